@@ -1,0 +1,183 @@
+"""Parameter inventory of the reference models, in struct-field DFS order.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Independent restatement of the layer lists in
+`diffusion.mojo:175-201,299-302` and `vae.mojo:94-112,194-219`; the product has its own table
+(csrc/model_spec.cpp, exported through `tsd_model_param_info`) and tests assert both agree.
+
+Every learnable field the reference allocates is listed, including the ones its forward never
+uses (`used=False`): `Linear.bias` when `use_bias=False` (helpers/utils.mojo:1939), the 1x1
+skip conv of a residual block with cin == cout (diffusion.mojo:42, vae.mojo:46).
+
+Synthetic init: conv kernel U(+-1/sqrt(cin*k*k)) (helpers/utils.mojo:1722-1724),
+conv bias 0 (:1717; App.A D17), linear weight and bias U(+-1/sqrt(in)) (App.A D18).
+"""
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+from . import rng
+
+
+@dataclass(frozen=True)
+class Param:
+    name: str
+    shape: Tuple[int, ...]
+    kind: str        # "conv_w" | "conv_b" | "lin_w" | "lin_b"
+    bound: float     # uniform init bound (0 => zeros)
+    used: bool = True
+
+    @property
+    def numel(self):
+        return int(np.prod(self.shape))
+
+
+def _conv(out: List[Param], name, cin, cout, k, used=True):
+    out.append(Param(name + ".kernel", (cout, cin, k, k), "conv_w", 1.0 / np.sqrt(cin * k * k), used))
+    out.append(Param(name + ".bias", (cout,), "conv_b", 0.0, used))
+
+
+def _lin(out: List[Param], name, fin, fout, use_bias=True, used=True):
+    b = 1.0 / np.sqrt(fin)
+    out.append(Param(name + ".weight", (fout, fin), "lin_w", b, used))
+    out.append(Param(name + ".bias", (fout,), "lin_b", b, used and use_bias))
+
+
+def _unet_res(out, name, cin, cout):  # diffusion.mojo:34-42
+    _conv(out, name + ".layer2", cin, cout, 3)
+    _lin(out, name + ".layer3", 1280, cout)
+    _conv(out, name + ".layer5", cout, cout, 3)
+    _conv(out, name + ".layer6", cin, cout, 1, used=(cin != cout))
+
+
+def _unet_attn(out, name, n_head, n_embed, d_ctx=768):  # diffusion.mojo:87-98
+    C = n_head * n_embed
+    _conv(out, name + ".layer2", C, C, 1)
+    _lin(out, name + ".layer4.in_proj", C, 3 * C, use_bias=False)
+    _lin(out, name + ".layer4.out_proj", C, C)
+    _lin(out, name + ".layer6.q_proj", C, C, use_bias=False)
+    _lin(out, name + ".layer6.k_proj", d_ctx, C, use_bias=False)
+    _lin(out, name + ".layer6.v_proj", d_ctx, C, use_bias=False)
+    _lin(out, name + ".layer6.out_proj", C, C)
+    _lin(out, name + ".layer8", C, 8 * C)
+    _lin(out, name + ".layer9", 4 * C, C)
+    _conv(out, name + ".layer10", C, C, 1)
+
+
+# (kind, args) per UNet layer, diffusion.mojo:177-201
+UNET_LAYERS = [
+    ("conv", (4, 320, 3, 1)),      # layer1
+    ("res", (320, 320)),           # layer2
+    ("attn", (8, 40)),             # layer3
+    ("conv", (320, 320, 3, 2)),    # layer4 (stride 2)
+    ("res", (320, 640)),           # layer5
+    ("attn", (8, 80)),             # layer6
+    ("conv", (640, 640, 3, 2)),    # layer7 (stride 2)
+    ("res", (640, 1280)),          # layer8
+    ("attn", (8, 160)),            # layer9
+    ("res", (2560, 1280)),         # layer10
+    ("attn", (8, 160)),            # layer11
+    ("res", (1920, 1280)),         # layer12
+    ("attn", (8, 160)),            # layer13
+    ("up", ()),                    # layer14
+    ("res", (1280, 640)),          # layer15 (declared cin < concatenated channels; App.A D11)
+    ("attn", (8, 80)),             # layer16
+    ("res", (960, 640)),           # layer17
+    ("attn", (8, 80)),             # layer18
+    ("up", ()),                    # layer19
+    ("res", (640, 320)),           # layer20 (App.A D11)
+    ("attn", (8, 40)),             # layer21
+    ("res", (640, 320)),           # layer22
+    ("attn", (8, 40)),             # layer23
+]
+
+
+def diffusion_params() -> List[Param]:
+    """`Diffusion` diffusion.mojo:299-302."""
+    out: List[Param] = []
+    _lin(out, "time_embed.layer1", 320, 1280)
+    _lin(out, "time_embed.layer2", 1280, 1280)
+    for i, (kind, a) in enumerate(UNET_LAYERS, start=1):
+        name = f"unet.layer{i}"
+        if kind == "conv":
+            _conv(out, name, a[0], a[1], a[2])
+        elif kind == "res":
+            _unet_res(out, name, *a)
+        elif kind == "attn":
+            _unet_attn(out, name, *a)
+    _conv(out, "final.layer2", 320, 4, 3)
+    return out
+
+
+def _vae_res(out, name, cin, cout):  # vae.mojo:39-46
+    _conv(out, name + ".conv1", cin, cout, 3)
+    _conv(out, name + ".conv2", cout, cout, 3)
+    _conv(out, name + ".res_conv_layer", cin, cout, 1, used=(cin != cout))
+
+
+def _vae_attn(out, name, C):  # vae.mojo:9-11
+    _lin(out, name + ".attention.in_proj", C, 3 * C)
+    _lin(out, name + ".attention.out_proj", C, C)
+
+
+# vae.mojo:194-219
+DECODER_LAYERS = [
+    ("conv", (4, 4, 1)), ("conv", (4, 512, 3)), ("res", (512, 512)), ("attn", (512,)),
+    ("res", (512, 512)), ("res", (512, 512)), ("res", (512, 512)), ("res", (512, 512)),
+    ("up", ()), ("conv", (512, 512, 3)), ("res", (512, 512)), ("res", (512, 512)), ("res", (512, 512)),
+    ("up", ()), ("conv", (512, 512, 3)), ("res", (512, 256)), ("res", (256, 256)), ("res", (256, 256)),
+    ("up", ()), ("conv", (256, 256, 3)), ("res", (256, 128)), ("res", (128, 128)), ("res", (128, 128)),
+    ("gn", (32, 128)), ("silu", ()), ("conv", (128, 3, 3)),
+]
+
+# vae.mojo:94-112 ; "conv_s2" = stride-2 3x3 conv after the asymmetric (0,1),(0,1) pad (:115-116)
+ENCODER_LAYERS = [
+    ("conv", (3, 128, 3)), ("res", (128, 128)), ("res", (128, 128)), ("conv_s2", (128, 128, 3)),
+    ("res", (128, 256)), ("res", (256, 256)), ("conv_s2", (256, 256, 3)),
+    ("res", (256, 512)), ("res", (512, 512)), ("conv_s2", (512, 512, 3)),
+    ("res", (512, 512)), ("res", (512, 512)), ("res", (512, 512)), ("attn", (512,)), ("res", (512, 512)),
+    ("gn", (32, 512)), ("silu", ()), ("conv", (512, 8, 3)), ("conv", (8, 8, 1)),
+]
+
+
+def _vae_params(layers) -> List[Param]:
+    out: List[Param] = []
+    for i, (kind, a) in enumerate(layers, start=1):
+        name = f"l{i}"
+        if kind in ("conv", "conv_s2"):
+            _conv(out, name, *a)
+        elif kind == "res":
+            _vae_res(out, name, *a)
+        elif kind == "attn":
+            _vae_attn(out, name, *a)
+    return out
+
+
+def decoder_params() -> List[Param]:
+    return _vae_params(DECODER_LAYERS)
+
+
+def encoder_params() -> List[Param]:
+    return _vae_params(ENCODER_LAYERS)
+
+
+MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3}
+
+
+def tensor_id(model: str, index: int) -> int:
+    """RNG tensor id of parameter `index` of `model` (shared convention with the product)."""
+    return MODEL_IDS[model] * 4096 + index
+
+
+def init_params(model: str, seed: int, only_used=False):
+    """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder') -> {name: array}."""
+    plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params}[model]()
+    out = {}
+    for i, p in enumerate(plist):
+        if only_used and not p.used:
+            continue
+        if p.bound == 0.0:
+            out[p.name] = np.zeros(p.shape, dtype=np.float32)
+        else:
+            out[p.name] = rng.uniform(seed, tensor_id(model, i), p.numel, p.bound).reshape(p.shape)
+    return out
