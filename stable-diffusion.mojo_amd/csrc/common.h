@@ -1,0 +1,180 @@
+// common.h - internal types shared by the host graph code and the HIP kernels of libtsd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tsd.h"
+
+typedef _Float16 half_t;
+
+// ---- error plumbing -------------------------------------------------------------------
+void tsd_set_error(const char* fmt, ...);
+#define TSD_FAIL(code, ...)      \
+  do {                           \
+    tsd_set_error(__VA_ARGS__);  \
+    return (code);               \
+  } while (0)
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess) TSD_FAIL(TSD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+#define TSD_TRY(expr)            \
+  do {                           \
+    int r__ = (expr);            \
+    if (r__ != TSD_OK) return r__; \
+  } while (0)
+
+// ---- workspace arena: stack allocator over one big device allocation ------------------
+// All kernels of a context run on one stream, so releasing to a mark and re-using the bytes is
+// ordered by the stream.  `planning` mode only tracks the high-water mark (no launches).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, top = 0, peak = 0;
+  bool planning = false;
+  size_t mark() const { return top; }
+  void release(size_t m) { top = m; }
+  void* alloc(size_t bytes) {
+    size_t a = (top + 255) & ~size_t(255);
+    size_t n = a + bytes;
+    if (n > peak) peak = n;
+    if (!planning && n > cap) return nullptr;
+    top = n;
+    return planning ? (void*)(uintptr_t)(0x1000 + a) : (void*)(base + a);
+  }
+};
+
+struct tsd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  Arena arena;
+  half_t* zeros = nullptr;  // 4 KiB of zeros: source for padded im2col taps / padded head dims
+  void* staging = nullptr;  // device staging for host<->device copies
+  size_t staging_cap = 0;
+  void* rccl_comm = nullptr;
+  void* rccl_lib = nullptr;
+  int nranks = 1, rank = 0;
+  bool launch() const { return !arena.planning; }
+};
+
+int ctx_reserve_arena(tsd_ctx* ctx, size_t bytes);
+int ctx_reserve_staging(tsd_ctx* ctx, size_t bytes);
+
+// ---- device tensor views (NHWC fp16 activations) ---------------------------------------
+struct Act {  // [B][H][W][C] with row pitch ld (elements) between pixels
+  half_t* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0, ld = 0;
+  int64_t pixels() const { return (int64_t)B * H * W; }
+};
+
+template <class T>
+static inline T* arena_alloc(tsd_ctx* ctx, int64_t n) {
+  return (T*)ctx->arena.alloc((size_t)n * sizeof(T));
+}
+static inline Act act_alloc(tsd_ctx* ctx, int B, int H, int W, int C) {
+  Act a;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.ld = C;
+  a.p = arena_alloc<half_t>(ctx, (int64_t)B * H * W * C);
+  return a;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- packed weights ------------------------------------------------------------------
+struct ConvW {  // fp16 [Opad][k*k][Ipad] (K-major for the implicit GEMM), fp32 bias [Opad]
+  const half_t* w = nullptr;
+  const float* b = nullptr;
+  int I = 0, O = 0, k = 0, Ipad = 0, Opad = 0;
+};
+struct LinW {  // fp16 [N][Kpad], fp32 bias [N] (nullptr when the reference passes use_bias=False)
+  const half_t* w = nullptr;
+  const float* b = nullptr;
+  int N = 0, K = 0, Kpad = 0;
+};
+
+// ---- GEMM / implicit-GEMM conv launcher (kernels_gemm.hip) ------------------------------
+enum : int {
+  EPI_BIAS_N = 1,    // + bias[n]
+  EPI_BIAS_M = 2,    // + bias[m]            (swapped-operand GEMMs, e.g. V^T projection)
+  EPI_ROWVEC = 4,    // + rowvec[(m / rows_per_batch) * rowvec_ld + n]   (time-embedding add)
+  EPI_RESIDUAL = 8,  // + R[m][n]
+  EPI_RES_UPS = 16,  // residual is read through a nearest-2x upsample of a (Ho/2, Wo/2) tensor
+  EPI_GEGLU = 32,    // out[m][n/2] = a * gelu_tanh(g) for interleaved (a,g) column pairs
+  EPI_OUT_F32 = 64,  // store fp32 instead of fp16
+};
+
+struct GemmArgs {
+  // "A" operand: rows m.  Dense mode: A0[m][k] for k < K0, A1[m][k-K0] for k >= K0 (concat).
+  const half_t* A0 = nullptr; int lda0 = 0; int K0 = 0;
+  const half_t* A1 = nullptr; int lda1 = 0;
+  // conv3x3 mode (conv != 0): A0 is NHWC [B][Hs][Ws][lda0]; output pixel m = (b*Ho+oy)*Wo+ox reads
+  // tap (kh,kw) at (oy*stride-pad+kh, ox*stride-pad+kw) of the (optionally 2x-upsampled) source.
+  int conv = 0, Hs = 0, Ws = 0, Ho = 0, Wo = 0, Cin = 0, stride = 1, pad = 1, ups = 0;
+  const half_t* Wt = nullptr; int ldw = 0;  // "W" operand [N][K]
+  int M = 0, N = 0, K = 0;
+  int batch = 1; int64_t sA = 0, sW = 0, sC = 0, sR = 0;  // element strides per batch
+  int epi = 0;
+  const float* bias = nullptr;
+  const float* rowvec = nullptr; int rowvec_ld = 0; int rows_per_batch = 1;
+  const half_t* R = nullptr; int ldr = 0;
+  void* C = nullptr; int ldc = 0;
+  float out_scale = 1.f;  // applied to the accumulator before bias/residual
+};
+int launch_gemm(tsd_ctx* ctx, const GemmArgs& a);
+
+// ---- other kernel launchers -----------------------------------------------------------
+// layout / elementwise (kernels_elementwise.hip)
+int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int Cuse, float scale,
+                               half_t* dst, int Cdst);
+int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst);
+int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int ld, float* dst);
+int launch_f32_to_f16_rows(tsd_ctx* ctx, const float* src, int64_t rows, int cols, half_t* dst, int ld_dst,
+                           int64_t rows_dst);  // zero-pads cols..ld_dst and rows..rows_dst
+int launch_f16_to_f32_rows(tsd_ctx* ctx, const half_t* src, int64_t rows, int cols, int ld_src, float* dst);
+int launch_unary_f32(tsd_ctx* ctx, int op, const float* x, int64_t n, float* y);  // 0 silu 1 gelu 2 rescale
+int launch_pad_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, int t, int b, int l, int r, float* y);
+int launch_upsample_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, float* y);
+int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols, float* y);
+int launch_softmax_rows_f16(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld);  // in place
+int launch_time_embedding(tsd_ctx* ctx, const float* t_dev, float t_scalar, int B, float* out);  // out [B][320]; t_dev NULL -> scalar
+int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
+                        int N, int silu_in, float* y, int ldy);
+int launch_fill_uniform(tsd_ctx* ctx, float* dst, int64_t n, uint64_t seed, uint64_t tensor_id, float bound);
+// weight packing: src fp32 reference layout -> packed fp16
+int launch_pack_conv(tsd_ctx* ctx, const float* src, int O, int I, int k, half_t* dst, int Opad, int Ipad);
+int launch_pack_linear(tsd_ctx* ctx, const float* src, int N, int K, half_t* dst, int Kpad, int geglu_interleave);
+int launch_pack_bias(tsd_ctx* ctx, const float* src, int N, float* dst, int Npad, int geglu_interleave);
+int launch_transpose_f32_to_f16(tsd_ctx* ctx, const float* src, int batch, int K, int N, half_t* dst, int Kpad,
+                                int Npad);
+int launch_ddpm_step(tsd_ctx* ctx, float* latents, const float* eps, const float* eps_uncond, float cfg_scale,
+                     const float* noise, int64_t n, float inv_sqrt_a, float sqrt_b, float c_x0, float c_xt,
+                     float sigma);
+int launch_add_noise(tsd_ctx* ctx, float* latents, const float* noise, int64_t n, float sa, float sb);
+int launch_encoder_sample(tsd_ctx* ctx, const float* moments_nhwc, int B, int HW, int ld, const float* noise_chw,
+                          float* latents_chw);
+
+// norms (kernels_norm.hip).  Dual source: channels [0,C0) from x0, [C0,C) from x1 (concat).
+struct NormSrc {
+  const half_t* x0 = nullptr; int ld0 = 0; int C0 = 0;
+  const half_t* x1 = nullptr; int ld1 = 0;
+};
+int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
+                     int silu, half_t* y, int ldy);
+int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy);
+
+// attention (kernels_attn.hip): fused flash attention for d_head in {40, 80, 160}.
+struct AttnArgs {
+  const half_t* Q = nullptr; int ldq = 0; int64_t sQ = 0;    // Q[b][s][h*d + j]
+  const half_t* K = nullptr; int ldk = 0; int64_t sK = 0;    // K[b][t][h*d + j]
+  const half_t* Vt = nullptr; int ldvt = 0; int64_t sVt = 0; // Vt[b][h*d + j][t]  (t contiguous)
+  half_t* O = nullptr; int ldo = 0; int64_t sO = 0;          // O[b][s][h*d + j]
+  int B = 0, H = 0, d = 0, Sq = 0, Sk = 0;
+  float scale = 1.f;
+};
+bool attn_fused_supported(int d);
+int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a);

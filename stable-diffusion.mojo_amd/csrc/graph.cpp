@@ -1,0 +1,402 @@
+// graph.cpp - block and module graphs of the hot path (host code; every op is a kernel launch on
+// the context stream, activations are NHWC fp16 views into the workspace arena).
+#include <math.h>
+
+#include "graph.h"
+
+#define CHECK_ALLOC(p) \
+  if (!(p)) TSD_FAIL(TSD_E_ALLOC, "workspace arena exhausted (%s:%d)", __FILE__, __LINE__)
+
+static int zero_async(tsd_ctx* ctx, void* p, size_t bytes) {
+  if (!ctx->launch()) return TSD_OK;
+  HIP_TRY(hipMemsetAsync(p, 0, bytes, ctx->stream));
+  return TSD_OK;
+}
+
+int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, int pad_br, int ups,
+              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy) {
+  if (w.k != 3) TSD_FAIL(TSD_E_SHAPE, "g_conv3x3: kernel size %d", w.k);
+  if (x.ld < w.Ipad) TSD_FAIL(TSD_E_SHAPE, "g_conv3x3: input pitch %d < padded Cin %d", x.ld, w.Ipad);
+  const int Hin = ups ? 2 * x.H : x.H, Win = ups ? 2 * x.W : x.W;
+  // Ho = floor((H + pad + pad_br - k)/s) + 1 (helpers/utils.mojo:1752-1758); pad = top/left, pad_br =
+  // bottom/right (equal for Conv2D's symmetric padding; (0,1) for the encoder's two_stride_pad, vae.mojo:115-116).
+  const int pad_total = pad + pad_br;
+  const int Ho = (Hin + pad_total - 3) / stride + 1, Wo = (Win + pad_total - 3) / stride + 1;
+  GemmArgs g;
+  g.A0 = x.p; g.lda0 = x.ld; g.conv = 1; g.Hs = x.H; g.Ws = x.W; g.Ho = Ho; g.Wo = Wo; g.Cin = w.Ipad;
+  g.stride = stride; g.pad = pad; g.ups = ups;
+  g.Wt = w.w; g.ldw = 9 * w.Ipad;
+  g.M = x.B * Ho * Wo; g.N = w.Opad; g.K = 9 * w.Ipad;
+  g.epi = EPI_BIAS_N; g.bias = w.b;
+  if (rowvec) { g.epi |= EPI_ROWVEC; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = Ho * Wo; }
+  if (res) { g.epi |= EPI_RESIDUAL | (res_ups ? EPI_RES_UPS : 0); g.R = res->p; g.ldr = res->ld; }
+  if (out_f32) g.epi |= EPI_OUT_F32;
+  g.C = y; g.ldc = ldy;
+  return launch_gemm(ctx, g);
+}
+
+int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
+             const half_t* res, int ldr, int epi_extra, void* y, int ldy) {
+  GemmArgs g;
+  g.A0 = a.p0; g.lda0 = a.ld0;
+  if (a.p1 && K > a.C0) { g.A1 = a.p1; g.lda1 = a.ld1; g.K0 = a.C0; }
+  g.Wt = w; g.ldw = ldw; g.M = (int)M; g.N = N; g.K = K;
+  g.epi = epi_extra;
+  if (bias) { g.epi |= EPI_BIAS_N; g.bias = bias; }
+  if (res) { g.epi |= EPI_RESIDUAL; g.R = res; g.ldr = ldr; }
+  g.C = y; g.ldc = ldy;
+  return launch_gemm(ctx, g);
+}
+
+static NormSrc norm_src(const CatSrc& x, int C) {
+  NormSrc s;
+  s.x0 = x.p0; s.ld0 = x.ld0; s.C0 = x.C0;
+  if (x.p1 && C > x.C0) { s.x1 = x.p1; s.ld1 = x.ld1; }
+  return s;
+}
+
+// `Unet_Residual_Block.forward` diffusion.mojo:54-72 / VAE `Res_Block.forward` vae.mojo:57-67
+int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
+               int tld, Act out) {
+  const int cin = w.cin, cout = w.cout;
+  if (cin % 64 || cout % 64) TSD_FAIL(TSD_E_SHAPE, "residual block: channels (%d,%d) must be multiples of 64", cin, cout);
+  if (cin > x.C0 + (x.p1 ? x.C1 : 0)) TSD_FAIL(TSD_E_SHAPE, "residual block: input has fewer than %d channels", cin);
+  if (x.p1 && cin > x.C0 && (x.C0 % 64)) TSD_FAIL(TSD_E_SHAPE, "residual block: concat split %d not a multiple of 64", x.C0);
+  if (!w.has_skip && (ups || (x.p1 && cin > x.C0))) TSD_FAIL(TSD_E_SHAPE, "residual block: identity skip needs a plain input");
+  const int H = ups ? 2 * Hin : Hin, W = ups ? 2 * Win : Win;
+  const size_t mark = ctx->arena.mark();
+  // GN -> SiLU (only the first cin channels are normalised/consumed: App.A D11)
+  Act h = act_alloc(ctx, B, Hin, Win, cin); CHECK_ALLOC(h.p);
+  TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, 1e-5f, 1.f, 1, h.p, h.ld));
+  Act t1 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(t1.p);
+  TSD_TRY(g_conv3x3(ctx, h, w.conv1, 1, 1, 1, ups, tvec ? tvec + w.time_off : nullptr, tld, nullptr, 0, false, t1.p, t1.ld));
+  Act h3 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(h3.p);
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, 1e-5f, 1.f, 1, h3.p, h3.ld));
+  Act r;
+  if (w.has_skip) {  // 1x1 conv on the raw input, at the INPUT resolution (commutes with nearest upsample)
+    r = act_alloc(ctx, B, Hin, Win, cout); CHECK_ALLOC(r.p);
+    TSD_TRY(g_linear(ctx, x, (int64_t)B * Hin * Win, w.skip.w, w.skip.Ipad, cout, w.skip.Ipad, w.skip.b, nullptr, 0, 0,
+                     r.p, r.ld));
+  } else {
+    r.p = const_cast<half_t*>(x.p0); r.ld = x.ld0; r.B = B; r.H = Hin; r.W = Win; r.C = cout;
+  }
+  TSD_TRY(g_conv3x3(ctx, h3, w.conv2, 1, 1, 1, 0, nullptr, 0, &r, ups, false, out.p, out.ld));
+  ctx->arena.release(mark);
+  return TSD_OK;
+}
+
+// `Unet_Attention_Block.forward` diffusion.mojo:112-147 on NHWC tokens
+int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out) {
+  const int C = w.C, B = x.B, S = x.H * x.W, d = w.n_embed, Hh = w.n_head;
+  const int64_t M = (int64_t)B * S;
+  if (C % 64 || x.C != C) TSD_FAIL(TSD_E_SHAPE, "attention block: C=%d (input %d) unsupported", C, x.C);
+  if (!attn_fused_supported(d)) TSD_FAIL(TSD_E_SHAPE, "attention block: head dim %d unsupported (40/80/160)", d);
+  if (S % 8) TSD_FAIL(TSD_E_SHAPE, "attention block: H*W=%d must be a multiple of 8", S);
+  const size_t mark = ctx->arena.mark();
+  const float scale = 1.f / sqrtf((float)d);  // helpers/attention.mojo:57-58
+  half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C));  // :89,:116
+  half_t* tok = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok);
+  CatSrc a; a.p0 = h0; a.ld0 = C; a.C0 = C;
+  TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C));  // :117
+  half_t* ln = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ln);
+  half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
+  const int Sp = round_up(S, 8);
+  half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * Sp); CHECK_ALLOC(vt);
+  half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
+  // ---- self attention (:122-126) ----
+  TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C));
+  a.p0 = ln;
+  TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C));  // q,k
+  {  // V^T[b] = W_v . ln_b^T  -> [B][C][S]
+    GemmArgs g;
+    g.A0 = w.sa_in.w + (int64_t)2 * C * w.sa_in.Kpad; g.lda0 = w.sa_in.Kpad; g.sA = 0;
+    g.Wt = ln; g.ldw = C; g.sW = (int64_t)S * C;
+    g.M = C; g.N = S; g.K = C; g.batch = B;
+    g.C = vt; g.ldc = Sp; g.sC = (int64_t)C * Sp;
+    TSD_TRY(launch_gemm(ctx, g));
+  }
+  AttnArgs fa;
+  fa.Q = qk; fa.ldq = 2 * C; fa.sQ = (int64_t)S * 2 * C;
+  fa.K = qk + C; fa.ldk = 2 * C; fa.sK = (int64_t)S * 2 * C;
+  fa.Vt = vt; fa.ldvt = Sp; fa.sVt = (int64_t)C * Sp;
+  fa.O = ao; fa.ldo = C; fa.sO = (int64_t)S * C;
+  fa.B = B; fa.H = Hh; fa.d = d; fa.Sq = S; fa.Sk = S; fa.scale = scale;
+  TSD_TRY(launch_flash_attention(ctx, fa));
+  half_t* tok2 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok2);
+  a.p0 = ao;
+  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C));
+  // ---- cross attention (:129-133) ----
+  TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C));
+  half_t* q = qk;  // reuse
+  a.p0 = ln;
+  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C));
+  half_t* kc = arena_alloc<half_t>(ctx, (int64_t)B * Tp * C); CHECK_ALLOC(kc);
+  half_t* vtc = arena_alloc<half_t>(ctx, (int64_t)B * C * Tp); CHECK_ALLOC(vtc);
+  {
+    GemmArgs g;  // K_c[b] = ctx_b . W_k^T -> [B][Tp][C]
+    g.A0 = ctx16; g.lda0 = w.ca_k.Kpad; g.sA = (int64_t)Tp * w.ca_k.Kpad;
+    g.Wt = w.ca_k.w; g.ldw = w.ca_k.Kpad;
+    g.M = Tp; g.N = C; g.K = w.ca_k.Kpad; g.batch = B;
+    g.C = kc; g.ldc = C; g.sC = (int64_t)Tp * C;
+    TSD_TRY(launch_gemm(ctx, g));
+    GemmArgs v;  // V_c^T[b] = W_v . ctx_b^T -> [B][C][Tp]
+    v.A0 = w.ca_v.w; v.lda0 = w.ca_v.Kpad; v.sA = 0;
+    v.Wt = ctx16; v.ldw = w.ca_v.Kpad; v.sW = (int64_t)Tp * w.ca_v.Kpad;
+    v.M = C; v.N = Tp; v.K = w.ca_v.Kpad; v.batch = B;
+    v.C = vtc; v.ldc = Tp; v.sC = (int64_t)C * Tp;
+    TSD_TRY(launch_gemm(ctx, v));
+  }
+  fa.Q = q; fa.ldq = C; fa.sQ = (int64_t)S * C;
+  fa.K = kc; fa.ldk = C; fa.sK = (int64_t)Tp * C;
+  fa.Vt = vtc; fa.ldvt = Tp; fa.sVt = (int64_t)C * Tp;
+  fa.Sk = T;
+  TSD_TRY(launch_flash_attention(ctx, fa));
+  half_t* tok3 = tok;  // tok (first residual) is dead after tok2 was produced
+  a.p0 = ao;
+  TSD_TRY(g_linear(ctx, a, M, w.ca_out.w, w.ca_out.Kpad, C, C, w.ca_out.b, tok2, C, 0, tok3, C));
+  // ---- GEGLU feed-forward (:136-143) ----
+  TSD_TRY(launch_layernorm(ctx, tok3, M, C, C, 1e-5f, ln, C));
+  half_t* gg = arena_alloc<half_t>(ctx, M * 4 * C); CHECK_ALLOC(gg);
+  a.p0 = ln;
+  TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C));
+  half_t* tok4 = tok2;  // tok2 is dead after tok3
+  CatSrc ag; ag.p0 = gg; ag.ld0 = 4 * C; ag.C0 = 4 * C;
+  TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C));
+  // ---- output 1x1 conv + long residual (:146) ----
+  a.p0 = tok4;
+  TSD_TRY(g_linear(ctx, a, M, w.conv_out.w, w.conv_out.Ipad, C, C, w.conv_out.b, x.p, x.ld, 0, out.p, out.ld));
+  ctx->arena.release(mark);
+  return TSD_OK;
+}
+
+// Attention core on projected q/k (token-major) and v^T (channel-major): fused flash kernel for the UNet
+// head dims, otherwise (one head, d % 64 == 0: the VAE's 512-wide head) scores are materialised like the
+// reference does (helpers/attention.mojo:46) - batched GEMM -> row softmax -> batched GEMM.
+int g_attn_core(tsd_ctx* ctx, const AttnArgs& fa) {
+  if (attn_fused_supported(fa.d)) return launch_flash_attention(ctx, fa);
+  if (fa.H != 1 || fa.d % 64 || fa.Sk % 64)
+    TSD_FAIL(TSD_E_SHAPE, "attention: heads=%d d_head=%d Tk=%d unsupported (fused: d in {40,80,160}; unfused: 1 head, "
+             "d%%64==0, Tk%%64==0)", fa.H, fa.d, fa.Sk);
+  const int B = fa.B, Sq = fa.Sq, Sk = fa.Sk, C = fa.d;
+  const size_t mark = ctx->arena.mark();
+  half_t* sc = arena_alloc<half_t>(ctx, (int64_t)B * Sq * Sk); CHECK_ALLOC(sc);
+  {
+    GemmArgs g;  // scores[b] = q_b k_b^T * scale
+    g.A0 = fa.Q; g.lda0 = fa.ldq; g.sA = fa.sQ;
+    g.Wt = fa.K; g.ldw = fa.ldk; g.sW = fa.sK;
+    g.M = Sq; g.N = Sk; g.K = C; g.batch = B;
+    g.out_scale = fa.scale;
+    g.C = sc; g.ldc = Sk; g.sC = (int64_t)Sq * Sk;
+    TSD_TRY(launch_gemm(ctx, g));
+  }
+  TSD_TRY(launch_softmax_rows_f16(ctx, sc, (int64_t)B * Sq, Sk, Sk));
+  {
+    GemmArgs g;  // o_b = P_b v_b
+    g.A0 = sc; g.lda0 = Sk; g.sA = (int64_t)Sq * Sk;
+    g.Wt = fa.Vt; g.ldw = fa.ldvt; g.sW = fa.sVt;
+    g.M = Sq; g.N = C; g.K = Sk; g.batch = B;
+    g.C = fa.O; g.ldc = fa.ldo; g.sC = fa.sO;
+    TSD_TRY(launch_gemm(ctx, g));
+  }
+  ctx->arena.release(mark);
+  return TSD_OK;
+}
+
+// q,k (token-major [B*S][2C]) and v^T ([B][C][Sp]) from a fused in_proj (3C, C) (helpers/attention.mojo:29)
+int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& in_proj, half_t* qk, half_t* vt,
+               int Sp) {
+  CatSrc a; a.p0 = x; a.ld0 = C; a.C0 = C;
+  TSD_TRY(g_linear(ctx, a, (int64_t)B * S, in_proj.w, in_proj.Kpad, 2 * C, in_proj.Kpad, in_proj.b, nullptr, 0, 0, qk,
+                   2 * C));
+  GemmArgs g;  // V^T[b] = W_v . x_b^T
+  g.A0 = in_proj.w + (int64_t)2 * C * in_proj.Kpad; g.lda0 = in_proj.Kpad; g.sA = 0;
+  g.Wt = x; g.ldw = C; g.sW = (int64_t)S * C;
+  g.M = C; g.N = S; g.K = in_proj.Kpad; g.batch = B;
+  if (in_proj.b) { g.epi = EPI_BIAS_M; g.bias = in_proj.b + 2 * C; }
+  g.C = vt; g.ldc = Sp; g.sC = (int64_t)C * Sp;
+  return launch_gemm(ctx, g);
+}
+
+// VAE `Attention_Block.forward` vae.mojo:17-27: GroupNorm(32) -> one head of width C -> + x
+int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act out) {
+  const int C = w.C, B = x.B, S = x.H * x.W;
+  const int64_t M = (int64_t)B * S;
+  if (C % 64 || S % 8) TSD_FAIL(TSD_E_SHAPE, "vae attention: C=%d, H*W=%d unsupported", C, S);
+  const size_t mark = ctx->arena.mark();
+  half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-5f, 1.f, 0, h0, C));
+  half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
+  half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * S); CHECK_ALLOC(vt);
+  half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
+  TSD_TRY(g_qkv_proj(ctx, h0, B, S, C, w.in_proj, qk, vt, S));
+  AttnArgs fa;
+  fa.Q = qk; fa.ldq = 2 * C; fa.sQ = (int64_t)S * 2 * C;
+  fa.K = qk + C; fa.ldk = 2 * C; fa.sK = (int64_t)S * 2 * C;
+  fa.Vt = vt; fa.ldvt = S; fa.sVt = (int64_t)C * S;
+  fa.O = ao; fa.ldo = C; fa.sO = (int64_t)S * C;
+  fa.B = B; fa.H = 1; fa.d = C; fa.Sq = S; fa.Sk = S; fa.scale = 1.f / sqrtf((float)C);
+  TSD_TRY(g_attn_core(ctx, fa));
+  CatSrc a; a.p0 = ao; a.ld0 = C; a.C0 = C;
+  TSD_TRY(g_linear(ctx, a, M, w.out_proj.w, w.out_proj.Kpad, C, C, w.out_proj.b, x.p, x.ld, 0, out.p, out.ld));
+  ctx->arena.release(mark);
+  return TSD_OK;
+}
+
+// ---- `Diffusion.forward` diffusion.mojo:309-318 -------------------------------------------------------
+int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
+                   int L, float* eps_out_chw) {
+  tsd_ctx* ctx = m->ctx;
+  const UNetW& u = m->unet;
+  if (L % 4) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 4", L);
+  // ---- time path (diffusion.mojo:17-21 and :61-62 for all nine residual blocks) ----
+  float* t1 = arena_alloc<float>(ctx, (int64_t)B * 1280); CHECK_ALLOC(t1);
+  float* time = arena_alloc<float>(ctx, (int64_t)B * 1280); CHECK_ALLOC(time);
+  float* tvec = arena_alloc<float>(ctx, (int64_t)B * u.tproj.N); CHECK_ALLOC(tvec);
+  TSD_TRY(launch_small_linear(ctx, temb, B, 320, 320, u.t1.w, u.t1.Kpad, u.t1.b, 1280, 0, t1, 1280));
+  TSD_TRY(launch_small_linear(ctx, t1, B, 1280, 1280, u.t2.w, u.t2.Kpad, u.t2.b, 1280, 1, time, 1280));
+  TSD_TRY(launch_small_linear(ctx, time, B, 1280, 1280, u.tproj.w, u.tproj.Kpad, u.tproj.b, u.tproj.N, 1, tvec,
+                              u.tproj.N));
+  const int tld = u.tproj.N;
+  // ---- input ----
+  Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
+  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
+  Act a[24];
+  auto alloc_out = [&](int i, int side, int C) -> int {
+    a[i] = act_alloc(ctx, B, side, side, C);
+    CHECK_ALLOC(a[i].p);
+    return TSD_OK;
+  };
+  const int L1 = L / 2, L2 = L / 4;
+  auto res = [&](int i, const CatSrc& src, int side_in, int ups) -> int {
+    const ResW& w = u.res[i - 1];
+    TSD_TRY(alloc_out(i, ups ? side_in * 2 : side_in, w.cout));
+    return g_resblock(ctx, src, B, side_in, side_in, ups, w, tvec, tld, a[i]);
+  };
+  auto attn = [&](int i) -> int {
+    TSD_TRY(alloc_out(i, a[i - 1].H, a[i - 1].C));
+    return g_unet_attn(ctx, a[i - 1], u.attn[i - 1], ctx16, T, Tp, a[i]);
+  };
+  // encoders (diffusion.mojo:236-250)
+  TSD_TRY(alloc_out(1, L, 320));
+  TSD_TRY(g_conv3x3(ctx, x0, u.conv1, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[1].p, a[1].ld));
+  TSD_TRY(res(2, cat1(a[1]), L, 0));
+  TSD_TRY(attn(3));
+  TSD_TRY(alloc_out(4, L1, 320));
+  TSD_TRY(g_conv3x3(ctx, a[3], u.conv4, 2, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[4].p, a[4].ld));
+  TSD_TRY(res(5, cat1(a[4]), L1, 0));
+  TSD_TRY(attn(6));
+  TSD_TRY(alloc_out(7, L2, 640));
+  TSD_TRY(g_conv3x3(ctx, a[6], u.conv7, 2, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[7].p, a[7].ld));
+  TSD_TRY(res(8, cat1(a[7]), L2, 0));
+  TSD_TRY(attn(9));
+  // decoders (diffusion.mojo:253-272); skip4 / skip2 are dead (App.A D11): layers 15 and 20 declare
+  // fewer input channels than the concat provides and only read the first in_channels.
+  TSD_TRY(res(10, cat2(a[9], a[9]), L2, 0));
+  TSD_TRY(attn(11));
+  TSD_TRY(res(12, cat2(a[11], a[7]), L2, 0));
+  TSD_TRY(attn(13));
+  TSD_TRY(res(15, cat1(a[13]), L2, 1));  // layer14 Upsample folded into the conv/residual addressing
+  a[14] = a[15];
+  TSD_TRY(attn(16));
+  TSD_TRY(res(17, cat2(a[16], a[4]), L1, 0));
+  TSD_TRY(attn(18));
+  TSD_TRY(res(20, cat1(a[18]), L1, 1));  // layer19 Upsample folded
+  a[19] = a[20];
+  TSD_TRY(attn(21));
+  TSD_TRY(res(22, cat2(a[21], a[1]), L, 0));
+  TSD_TRY(attn(23));
+  // `UNet_Output_Layer` diffusion.mojo:287-291: GroupNorm(320 groups) -> SiLU -> Conv3x3(320,4)
+  Act hf = act_alloc(ctx, B, L, L, 320); CHECK_ALLOC(hf.p);
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(a[23]), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld));
+  float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
+  TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
+  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));
+  return TSD_OK;
+}
+
+// ---- VAE (vae.mojo:131-159, :221-250) -------------------------------------------------------------------
+static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, bool final_f32, float* out_nhwc_f32,
+                   int* out_side, int* out_ld) {
+  tsd_ctx* ctx = m->ctx;
+  const VaeW& v = m->vae;
+  const int B = cur.B;
+  int pending_up = 0;
+  for (int i = 0; i < n_layers; i++) {
+    const LayerDef& l = layers[i];
+    const bool last = (i == n_layers - 1);
+    if (l.kind == L_UP) { pending_up = 1; continue; }
+    if (l.kind == L_SILU) continue;  // fused into the preceding GroupNorm
+    if (l.kind == L_GN) {
+      Act y = act_alloc(ctx, B, cur.H, cur.W, l.b); CHECK_ALLOC(y.p);
+      const int silu = (i + 1 < n_layers && layers[i + 1].kind == L_SILU) ? 1 : 0;
+      TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), l.b), B, cur.H * cur.W, l.b, l.a, 1e-5f, 1.f, silu, y.p, y.ld));
+      cur = y;
+      continue;
+    }
+    if (l.kind == L_CONV || l.kind == L_CONV_S2) {
+      const ConvW& w = v.conv[i];
+      const int stride = l.kind == L_CONV_S2 ? 2 : 1;
+      const int pad = l.kind == L_CONV_S2 ? 0 : (l.c == 3 ? 1 : 0);
+      const int pad_br = l.kind == L_CONV_S2 ? 1 : pad;  // two_stride_pad (0,1),(0,1), vae.mojo:115-116
+      const int side_in = pending_up ? cur.H * 2 : cur.H;
+      const int side = l.kind == L_CONV_S2 ? side_in / 2 : side_in;
+      if (last && final_f32) {
+        if (l.c == 3) TSD_TRY(g_conv3x3(ctx, cur, w, stride, pad, pad_br, pending_up, nullptr, 0, nullptr, 0, true, out_nhwc_f32, w.Opad));
+        else {
+          GemmArgs g;
+          g.A0 = cur.p; g.lda0 = cur.ld; g.Wt = w.w; g.ldw = w.Ipad; g.M = B * side * side; g.N = w.Opad; g.K = w.Ipad;
+          g.epi = EPI_BIAS_N | EPI_OUT_F32; g.bias = w.b; g.C = out_nhwc_f32; g.ldc = w.Opad;
+          TSD_TRY(launch_gemm(ctx, g));
+        }
+        *out_side = side; *out_ld = w.Opad;
+        return TSD_OK;
+      }
+      Act y = act_alloc(ctx, B, side, side, w.Opad); CHECK_ALLOC(y.p);
+      if (l.c == 3) TSD_TRY(g_conv3x3(ctx, cur, w, stride, pad, pad_br, pending_up, nullptr, 0, nullptr, 0, false, y.p, y.ld));
+      else TSD_TRY(g_linear(ctx, cat1(cur), (int64_t)B * side * side, w.w, w.Ipad, w.Opad, w.Ipad, w.b, nullptr, 0, 0, y.p, y.ld));
+      pending_up = 0;
+      cur = y;
+      continue;
+    }
+    if (pending_up) TSD_FAIL(TSD_E_STATE, "vae: upsample must be followed by a conv");
+    if (l.kind == L_RES) {
+      Act y = act_alloc(ctx, B, cur.H, cur.W, l.b); CHECK_ALLOC(y.p);
+      TSD_TRY(g_resblock(ctx, cat1(cur), B, cur.H, cur.W, 0, v.res[i], nullptr, 0, y));
+      cur = y;
+    } else if (l.kind == L_ATTN) {
+      Act y = act_alloc(ctx, B, cur.H, cur.W, l.a); CHECK_ALLOC(y.p);
+      TSD_TRY(g_vae_attn(ctx, cur, v.attn[i], y));
+      cur = y;
+    }
+  }
+  return TSD_OK;
+}
+
+int g_decoder_forward(tsd_model* m, const float* latents_chw, int B, int L, float* images_chw) {
+  tsd_ctx* ctx = m->ctx;
+  if (L % 8) TSD_FAIL(TSD_E_SHAPE, "decoder: latent side %d must be a multiple of 8", L);
+  Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
+  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f / 0.18215f, x0.p, 64));  // vae.mojo:222
+  const int S = 8 * L;
+  float* img = arena_alloc<float>(ctx, (int64_t)B * S * S * 4); CHECK_ALLOC(img);
+  int side = 0, ld = 0;
+  TSD_TRY(run_vae(m, DECODER_LAYERS, 26, x0, true, img, &side, &ld));
+  if (ctx->launch() && (side != S || ld != 4)) TSD_FAIL(TSD_E_STATE, "decoder: unexpected output %d/%d", side, ld);
+  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, img, B, 3, S, S, 4, images_chw));
+  return TSD_OK;
+}
+
+int g_encoder_forward(tsd_model* m, const float* images_chw, const float* noise_chw, int B, int S, float* latents_chw) {
+  tsd_ctx* ctx = m->ctx;
+  if (S % 64) TSD_FAIL(TSD_E_SHAPE, "encoder: image side %d must be a multiple of 64", S);
+  Act x0 = act_alloc(ctx, B, S, S, 64); CHECK_ALLOC(x0.p);
+  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, images_chw, B, 3, S, S, 3, 1.f, x0.p, 64));
+  const int L = S / 8;
+  float* mom = arena_alloc<float>(ctx, (int64_t)B * L * L * 8); CHECK_ALLOC(mom);
+  int side = 0, ld = 0;
+  TSD_TRY(run_vae(m, ENCODER_LAYERS, 19, x0, true, mom, &side, &ld));
+  if (ctx->launch() && (side != L || ld != 8)) TSD_FAIL(TSD_E_STATE, "encoder: unexpected output %d/%d", side, ld);
+  TSD_TRY(launch_encoder_sample(ctx, mom, B, L * L, 8, noise_chw, latents_chw));
+  return TSD_OK;
+}

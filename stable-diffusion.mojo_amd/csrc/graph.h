@@ -1,0 +1,51 @@
+// graph.h - host-side graph of the hot path: block and module forwards enqueue kernels on the
+// context stream; activations live in the workspace arena as NHWC fp16.
+#pragma once
+#include "model.h"
+
+// channel-concat view of up to two NHWC tensors with identical (B,H,W) (diffusion.mojo:253-270)
+struct CatSrc {
+  const half_t* p0 = nullptr; int ld0 = 0; int C0 = 0;
+  const half_t* p1 = nullptr; int ld1 = 0; int C1 = 0;
+};
+static inline CatSrc cat1(const Act& a) { CatSrc c; c.p0 = a.p; c.ld0 = a.ld; c.C0 = a.C; return c; }
+static inline CatSrc cat2(const Act& a, const Act& b) {
+  CatSrc c = cat1(a); c.p1 = b.p; c.ld1 = b.ld; c.C1 = b.C; return c;
+}
+
+// y = conv3x3(x) (+bias) (+rowvec per sample) (+residual); `ups`: x is read through a nearest-2x upsample.
+int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, int pad_br, int ups,
+              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy);
+// y[M][N] = A[M][K] . W^T (+bias) (+residual) ; A may be a concat view
+int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
+             const half_t* res, int ldr, int epi_extra, void* y, int ldy);
+
+int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
+               int tld, Act out);
+int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out);
+int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act out);
+int g_attn_core(tsd_ctx* ctx, const AttnArgs& fa);
+int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& in_proj, half_t* qk, half_t* vt, int Sp);
+
+// module forwards on device buffers
+// latents: fp32 CHW [B,4,L,L]; context16: fp16 [B][Tp][768]; temb: fp32 [B][320]; eps_out: fp32 CHW [B,4,L,L]
+int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
+                   int L, float* eps_out_chw);
+int g_decoder_forward(tsd_model* m, const float* latents_chw, int B, int L, float* images_chw);
+int g_encoder_forward(tsd_model* m, const float* images_chw, const float* noise_chw, int B, int S, float* latents_chw);
+
+// run `fn` once in planning mode to size the arena, reserve it, then for real
+template <class F>
+int run_planned(tsd_ctx* ctx, F&& fn) {
+  Arena& a = ctx->arena;
+  a.planning = true; a.top = 0; a.peak = 0;
+  int r = fn();
+  a.planning = false;
+  const size_t need = a.peak;
+  a.top = 0; a.peak = 0;
+  if (r != TSD_OK) return r;
+  TSD_TRY(ctx_reserve_arena(ctx, need));
+  r = fn();
+  a.top = 0;
+  return r;
+}

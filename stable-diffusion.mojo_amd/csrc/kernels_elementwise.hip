@@ -1,0 +1,446 @@
+// kernels_elementwise.hip - HBM-bound helpers: boundary layout conversion (reference CHW fp32 <->
+// device NHWC fp16), op-level fp32 elementwise ops, row softmax, time embedding, the tiny
+// M<=16 linears of the time path, weight packing, counter-RNG init and the DDPM update.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define GRID1D(n, bs) dim3((unsigned)std::min<int64_t>(((n) + (bs)-1) / (bs), 1 << 20))
+#include <algorithm>
+
+// ---- boundary layout conversion ------------------------------------
+// [B][C][H][W] fp32 -> [B][H][W][Cdst] fp16; channels >= Cuse are zero (K padding for the
+// implicit GEMM); value * scale (Decoder's x/0.18215, vae.mojo:222, folded here).
+__global__ void k_chw_to_nhwc(const float* __restrict__ src, int C, int HW, int Cuse, float scale,
+                              half_t* __restrict__ dst, int Cdst, int64_t total_chunks) {
+  const int cchunks = Cdst >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // pixel fastest so that the strided fp32 reads of neighbouring threads coalesce
+    const int64_t pix_total = total_chunks / cchunks;
+    const int cc = (int)(i / pix_total);
+    const int64_t pixg = i - (int64_t)cc * pix_total;  // b*HW + pix
+    const int64_t b = pixg / HW;
+    const int64_t pix = pixg - b * HW;
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = cc * 8 + j;
+      v[j] = (c < Cuse) ? (half_t)(src[(b * C + c) * HW + pix] * scale) : (half_t)0.f;
+    }
+    *(h8*)(dst + pixg * Cdst + cc * 8) = v;
+  }
+}
+int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int Cuse, float scale,
+                               half_t* dst, int Cdst) {
+  if (Cdst % 8) TSD_FAIL(TSD_E_SHAPE, "nhwc channel pitch %d not a multiple of 8", Cdst);
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)B * H * W * (Cdst / 8);
+  hipLaunchKernelGGL(k_chw_to_nhwc, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, Cuse, scale, dst,
+                     Cdst, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+template <class T>
+__global__ void k_nhwc_to_chw(const T* __restrict__ src, int C, int HW, int ld, float* __restrict__ dst,
+                              int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % HW;
+    const int64_t bc = i / HW;
+    const int c = (int)(bc % C);
+    const int64_t b = bc / C;
+    dst[i] = (float)src[(b * HW + pix) * ld + c];
+  }
+}
+int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)B * C * H * W;
+  hipLaunchKernelGGL(k_nhwc_to_chw<half_t>, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, ld, dst,
+                     total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int ld, float* dst) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)B * C * H * W;
+  hipLaunchKernelGGL(k_nhwc_to_chw<float>, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, ld, dst,
+                     total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// rows x cols fp32 -> fp16 [rows_dst][ld_dst], zero padded
+__global__ void k_f32_to_f16_rows(const float* __restrict__ src, int64_t rows, int cols, half_t* __restrict__ dst,
+                                  int ld, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ld;
+    const int c = (int)(i - r * ld);
+    dst[i] = (r < rows && c < cols) ? (half_t)src[r * cols + c] : (half_t)0.f;
+  }
+}
+int launch_f32_to_f16_rows(tsd_ctx* ctx, const float* src, int64_t rows, int cols, half_t* dst, int ld_dst,
+                           int64_t rows_dst) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = rows_dst * ld_dst;
+  hipLaunchKernelGGL(k_f32_to_f16_rows, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, rows, cols, dst, ld_dst,
+                     total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+__global__ void k_f16_to_f32_rows(const half_t* __restrict__ src, int cols, int ld, float* __restrict__ dst,
+                                  int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    dst[i] = (float)src[r * ld + c];
+  }
+}
+int launch_f16_to_f32_rows(tsd_ctx* ctx, const half_t* src, int64_t rows, int cols, int ld_src, float* dst) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = rows * cols;
+  hipLaunchKernelGGL(k_f16_to_f32_rows, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, cols, ld_src, dst, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- op-level fp32 elementwise ------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }  // helpers/utils.mojo:1898
+__device__ __forceinline__ float gelu_f(float x) {                                   // helpers/utils.mojo:1914
+  return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__global__ void k_unary(int op, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    float r;
+    if (op == 0) r = v / (1.f + expf(-v));
+    else if (op == 1) r = gelu_f(v);
+    else r = fminf(fmaxf((v + 1.f) * 127.5f, 0.f), 255.f);  // pipeline.mojo:127
+    y[i] = r;
+  }
+}
+int launch_unary_f32(tsd_ctx* ctx, int op, const float* x, int64_t n, float* y) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_unary, GRID1D(n, 256), dim3(256), 0, ctx->stream, op, x, n, y);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+__global__ void k_pad(const float* __restrict__ x, int C, int H, int W, int t, int l, int Ho, int Wo,
+                      float* __restrict__ y, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const int oy = (int)((i / Wo) % Ho);
+    const int c = (int)(i / ((int64_t)Wo * Ho));
+    const int iy = oy - t, ix = ox - l;
+    y[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? x[((int64_t)c * H + iy) * W + ix] : 0.f;
+  }
+}
+int launch_pad_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, int t, int b, int l, int r, float* y) {
+  if (!ctx->launch()) return TSD_OK;
+  const int Ho = H + t + b, Wo = W + l + r;
+  const int64_t total = (int64_t)C * Ho * Wo;
+  hipLaunchKernelGGL(k_pad, GRID1D(total, 256), dim3(256), 0, ctx->stream, x, C, H, W, t, l, Ho, Wo, y, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+__global__ void k_upsample(const float* __restrict__ x, int H, int W, float* __restrict__ y, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % (2 * W));
+    const int oy = (int)((i / (2 * W)) % (2 * H));
+    const int64_t c = i / ((int64_t)4 * W * H);
+    y[i] = x[(c * H + (oy >> 1)) * W + (ox >> 1)];
+  }
+}
+int launch_upsample_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, float* y) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)C * H * W * 4;
+  hipLaunchKernelGGL(k_upsample, GRID1D(total, 256), dim3(256), 0, ctx->stream, x, H, W, y, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- row softmax (helpers/utils.mojo:411-448 over the key axis, with max subtraction) ------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_softmax_rows(const T* __restrict__ x, int cols, int ldx, T* __restrict__ y,
+                                                      int ldy) {
+  __shared__ float red[8];
+  const int64_t row = blockIdx.x;
+  const T* xr = x + row * ldx;
+  T* yr = y + row * ldy;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -3.0e38f;
+  for (int c = tid; c < cols; c += 256) m = fmaxf(m, (float)xr[c]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int c = tid; c < cols; c += 256) s += __expf((float)xr[c] - m);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  s = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.f / s;
+  for (int c = tid; c < cols; c += 256) yr[c] = (T)(__expf((float)xr[c] - m) * inv);
+}
+int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols, float* y) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_softmax_rows<float>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, x, cols, cols, y, cols);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+int launch_softmax_rows_f16(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_softmax_rows<half_t>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const half_t*)x, cols,
+                     ld, x, ld);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- time embedding (helpers/utils.mojo:353-370, build semantics App.A D9) -----------------------
+__global__ void k_time_embedding(const float* __restrict__ t, float t_scalar, float* __restrict__ out) {
+  const int b = blockIdx.x, i = threadIdx.x;  // 160 threads
+  if (i >= 160) return;
+  const float f = (float)pow(10000.0, -(double)i / 160.0);
+  const float x = f * (t ? t[b] : t_scalar);
+  out[b * 320 + i] = (float)cos((double)x);
+  out[b * 320 + 160 + i] = (float)sin((double)x);
+}
+int launch_time_embedding(tsd_ctx* ctx, const float* t, float t_scalar, int B, float* out) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_time_embedding, dim3(B), dim3(192), 0, ctx->stream, t, t_scalar, out);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- tiny-M linear (time MLP and the nine 1280->C time projections; SURVEY.md App.D K8) ----------
+// y[b][n] = sum_k act(x[b][k]) * W[n][k] + bias[n], B <= 16.  Weights are streamed once
+// (HBM-bound GEMV); act(x) is staged in LDS per block.
+constexpr int SL_MAXB = 16;
+__global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ x, int B, int K, int ldx,
+                                                      const half_t* __restrict__ w, int ldw,
+                                                      const float* __restrict__ bias, int N, int silu_in,
+                                                      float* __restrict__ y, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char smem_sl[];
+  float* xs = (float*)smem_sl;  // [B][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < B * K; i += 256) {
+    const int b = i / K, k = i - b * K;
+    float v = x[(int64_t)b * ldx + k];
+    xs[i] = silu_in ? silu_f(v) : v;
+  }
+  __syncthreads();
+  const int n_per_block = 16;
+  for (int j = wave; j < n_per_block; j += 4) {
+    const int n = blockIdx.x * n_per_block + j;
+    if (n >= N) break;
+    float acc[SL_MAXB];
+#pragma unroll
+    for (int b = 0; b < SL_MAXB; b++) acc[b] = 0.f;
+    const half_t* wr = w + (int64_t)n * ldw;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+      const h8 wv = *(const h8*)(wr + k0);
+#pragma unroll
+      for (int b = 0; b < SL_MAXB; b++) {
+        if (b < B) {
+          const f4 x0 = *(const f4*)(xs + b * K + k0), x1 = *(const f4*)(xs + b * K + k0 + 4);
+          acc[b] += (float)wv[0] * x0[0] + (float)wv[1] * x0[1] + (float)wv[2] * x0[2] + (float)wv[3] * x0[3] +
+                    (float)wv[4] * x1[0] + (float)wv[5] * x1[1] + (float)wv[6] * x1[2] + (float)wv[7] * x1[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < SL_MAXB; b++) {
+      if (b < B) {
+        const float s = wave_sum(acc[b]);
+        if (lane == 0) y[(int64_t)b * ldy + n] = s + (bias ? bias[n] : 0.f);
+      }
+    }
+  }
+}
+int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
+                        int N, int silu_in, float* y, int ldy) {
+  if (B > SL_MAXB) TSD_FAIL(TSD_E_SHAPE, "small_linear: B=%d > %d", B, SL_MAXB);
+  if (K % 8) TSD_FAIL(TSD_E_SHAPE, "small_linear: K=%d not a multiple of 8", K);
+  if (!ctx->launch()) return TSD_OK;
+  const size_t lds = (size_t)B * K * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_small_linear, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  if (lds > 160 * 1024) TSD_FAIL(TSD_E_SHAPE, "small_linear: B*K too large for LDS");
+  hipLaunchKernelGGL(k_small_linear, dim3(ceil_div(N, 16)), dim3(256), lds, ctx->stream, x, B, K, ldx, w, ldw, bias, N,
+                     silu_in, y, ldy);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- counter RNG (bit-identical to tsd/rng.py and oracle/rng.py) ---------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+__global__ void k_fill_uniform(float* __restrict__ dst, int64_t n, uint64_t base, float bound) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t h = mix64((uint64_t)i + base);
+    const float u = (float)(uint32_t)(h >> 40);                   // 24 bits, exact
+    const float v = __fsub_rn(__fmul_rn(u, 1.1920928955078125e-07f), 1.0f);  // u*2^-23 - 1, exact
+    dst[i] = __fmul_rn(v, bound);
+  }
+}
+int launch_fill_uniform(tsd_ctx* ctx, float* dst, int64_t n, uint64_t seed, uint64_t tensor_id, float bound) {
+  if (!ctx->launch()) return TSD_OK;
+  const uint64_t base = seed * 0x9E3779B97F4A7C15ull + tensor_id * 0xBF58476D1CE4E5B9ull;
+  hipLaunchKernelGGL(k_fill_uniform, GRID1D(n, 256), dim3(256), 0, ctx->stream, dst, n, base, bound);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+// conv (O,I,k,k) fp32 -> fp16 [Opad][k*k][Ipad]: K index = tap*Ipad + i (tap-major so a 64-wide
+// K chunk stays inside one tap and reads 128 contiguous NHWC bytes).
+__global__ void k_pack_conv(const float* __restrict__ src, int O, int I, int kk, half_t* __restrict__ dst, int Ipad,
+                            int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ipad);
+    const int tap = (int)((i / Ipad) % kk);
+    const int o = (int)(i / ((int64_t)Ipad * kk));
+    dst[i] = (o < O && ci < I) ? (half_t)src[((int64_t)o * I + ci) * kk + tap] : (half_t)0.f;
+  }
+}
+int launch_pack_conv(tsd_ctx* ctx, const float* src, int O, int I, int k, half_t* dst, int Opad, int Ipad) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)Opad * k * k * Ipad;
+  hipLaunchKernelGGL(k_pack_conv, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, O, I, k * k, dst, Ipad, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+// linear (N,K) fp32 -> fp16 [N][Kpad].  geglu_interleave: packed row 2q = row q ("a" half),
+// 2q+1 = row N/2+q ("gate" half) so the GEMM epilogue sees (a,g) pairs in adjacent columns
+// (`chunk(2,2)` + `out*gelu(gate)`, diffusion.mojo:138-141).
+__global__ void k_pack_linear(const float* __restrict__ src, int N, int K, half_t* __restrict__ dst, int Kpad,
+                              int inter, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kpad);
+    const int r = (int)(i / Kpad);
+    const int sr = inter ? ((r & 1) ? N / 2 + (r >> 1) : (r >> 1)) : r;
+    dst[i] = (k < K) ? (half_t)src[(int64_t)sr * K + k] : (half_t)0.f;
+  }
+}
+int launch_pack_linear(tsd_ctx* ctx, const float* src, int N, int K, half_t* dst, int Kpad, int geglu_interleave) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)N * Kpad;
+  hipLaunchKernelGGL(k_pack_linear, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, N, K, dst, Kpad,
+                     geglu_interleave, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+__global__ void k_pack_bias(const float* __restrict__ src, int N, float* __restrict__ dst, int Npad, int inter) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= Npad) return;
+  const int sr = inter ? ((r & 1) ? N / 2 + (r >> 1) : (r >> 1)) : r;
+  dst[r] = (r < N) ? src[sr] : 0.f;
+}
+int launch_pack_bias(tsd_ctx* ctx, const float* src, int N, float* dst, int Npad, int geglu_interleave) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_pack_bias, dim3(ceil_div(Npad, 256)), dim3(256), 0, ctx->stream, src, N, dst, Npad,
+                     geglu_interleave);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- DDPM update + CFG combine (sampler.mojo:75-109, pipeline.mojo:117-119; App.D K9) ------------
+__global__ void k_ddpm_step(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ eps_u,
+                            float cfg_scale, const float* __restrict__ noise, int64_t n, float sa, float sb,
+                            float c_x0, float c_xt, float sigma) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float e = eps[i];
+    if (eps_u) {
+      const float u = eps_u[i];
+      e = (e - u) * cfg_scale + u;
+    }
+    const float xv = x[i];
+    const float x0 = (xv - e * sb) / sa;
+    float o = x0 * c_x0 + xv * c_xt;
+    if (noise) o += noise[i] * sigma;
+    x[i] = o;
+  }
+}
+int launch_ddpm_step(tsd_ctx* ctx, float* latents, const float* eps, const float* eps_uncond, float cfg_scale,
+                     const float* noise, int64_t n, float sa, float sb, float c_x0, float c_xt, float sigma) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_ddpm_step, GRID1D(n, 256), dim3(256), 0, ctx->stream, latents, eps, eps_uncond, cfg_scale,
+                     noise, n, sa, sb, c_x0, c_xt, sigma);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+__global__ void k_add_noise(float* __restrict__ x, const float* __restrict__ noise, int64_t n, float sa, float sb) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = x[i] * sa + noise[i] * sb;
+}
+int launch_add_noise(tsd_ctx* ctx, float* latents, const float* noise, int64_t n, float sa, float sb) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_add_noise, GRID1D(n, 256), dim3(256), 0, ctx->stream, latents, noise, n, sa, sb);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+// `Encoder.metrics_evals` vae.mojo:118-129: moments NHWC fp32 [B][HW][ld] (mean ch 0..3, logvar 4..7)
+__global__ void k_encoder_sample(const float* __restrict__ mom, int HW, int ld, const float* __restrict__ noise,
+                                 float* __restrict__ out, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % HW;
+    const int c = (int)((i / HW) % 4);
+    const int64_t b = i / ((int64_t)4 * HW);
+    const float* mp = mom + (b * HW + pix) * ld;
+    const float mean = mp[c];
+    const float lv = fminf(fmaxf(mp[4 + c], -30.f), 20.f);
+    const float sd = sqrtf(expf(lv));
+    out[i] = (mean + noise[i] * sd) * 0.18215f;
+  }
+}
+int launch_encoder_sample(tsd_ctx* ctx, const float* moments_nhwc, int B, int HW, int ld, const float* noise_chw,
+                          float* latents_chw) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)B * 4 * HW;
+  hipLaunchKernelGGL(k_encoder_sample, GRID1D(total, 256), dim3(256), 0, ctx->stream, moments_nhwc, HW, ld, noise_chw,
+                     latents_chw, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// (batch,K,N) fp32 -> fp16 [batch][Npad][Kpad] (zero padded): the K-major "W" operand of `Matrix.matmul`
+// (helpers/utils.mojo:1549-1569).
+__global__ void k_transpose_to_f16(const float* __restrict__ src, int K, int N, half_t* __restrict__ dst, int Kpad,
+                                   int Npad, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kpad);
+    const int n = (int)((i / Kpad) % Npad);
+    const int64_t b = i / ((int64_t)Kpad * Npad);
+    dst[i] = (k < K && n < N) ? (half_t)src[(b * K + k) * N + n] : (half_t)0.f;
+  }
+}
+int launch_transpose_f32_to_f16(tsd_ctx* ctx, const float* src, int batch, int K, int N, half_t* dst, int Kpad,
+                                int Npad) {
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)batch * Kpad * Npad;
+  hipLaunchKernelGGL(k_transpose_to_f16, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, K, N, dst, Kpad, Npad,
+                     total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}

@@ -1,0 +1,358 @@
+// kernels_gemm.hip - fp16 MFMA GEMM and implicit-GEMM 3x3 convolution for gfx950 (CDNA4).
+//
+// Replaces the reference's `Matrix.matmul` (helpers/utils.mojo:1549-1569), `Linear.forward`
+// (:1954-1976) and `Conv2D.forward` (:1738-1811, incl. `Matrix.pad` :1383-1413 folded into the
+// tap addressing and `Upsample` :1989-2010 folded into the source addressing).
+//
+// C[m][n] = epilogue( sum_k A[m][k] * W[n][k] )       ("NT": both operands K-contiguous)
+//   dense : A[m][k] row-major (optionally the channel-concat of two tensors)
+//   conv  : A row m = output pixel (b,oy,ox); k = (tap, cin) with the NHWC source read at
+//           (oy*stride-pad+kh, ox*stride-pad+kw); out-of-image taps read a zero page.
+//
+// Design (CDNA4, wave64):
+//   * v_mfma_f32_16x16x32_f16, operands swapped (D = Wfrag x Afrag^T) so each lane ends up with
+//     ONE output row m and 4*FN CONSECUTIVE output columns n -> contiguous 8-byte stores per
+//     fragment and 4*FN*2 contiguous bytes per lane.  The column permutation that makes the
+//     4*FN columns consecutive is applied for free on the SOURCE address of the W-tile load.
+//   * Tiles staged with global_load_lds_dwordx4 (16 B/lane DMA straight into LDS, no VGPR
+//     round trip), 128-B rows XOR-swizzled by (row & 7) on the source side so every
+//     ds_read_b128 fragment read is bank-conflict-free; double-buffered, one barrier per K-tile.
+//   * XCD-aware bijective block remap so tiles sharing an A panel hit the same per-XCD L2.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct GemmK {
+  const half_t* A0; const half_t* A1; const half_t* Wt; const half_t* R; const half_t* zeros;
+  const float* bias; const float* rowvec;
+  void* C;
+  long long sA, sW, sC, sR;
+  int lda0, lda1, K0, ldw, ldr, ldc, rowvec_ld, rows_per_batch;
+  int M, N, K;
+  int Hs, Ws, Ho, Wo, Cin, stride, pad, ups;
+  int epi, tiles_n;
+  float out_scale;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float c = 0.7978845608028654f;  // sqrt(2/pi), helpers/utils.mojo:1914
+  float u = c * (x + 0.044715f * x * x * x);
+  float e = __expf(2.f * u);  // tanh(u) = 1 - 2/(e^{2u}+1)
+  float t = 1.f - 2.f / (e + 1.f);
+  return 0.5f * x * (1.f + t);
+}
+
+template <int WGM, int WGN, int FM, int FN, bool CONV>
+__global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_kernel(const GemmK p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
+  constexpr int BMw = FM * 16, BNw = FN * 16;
+  constexpr int A_INSTR = BM / 8, W_INSTR = BN / 8;  // 1-KiB wave-instructions per tile
+  constexpr int A_PW = (A_INSTR + NW - 1) / NW, W_PW = (W_INSTR + NW - 1) / NW;
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // XCD-aware bijective remap (block b runs on XCD b%8; give each XCD a contiguous tile range).
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.y;
+  const half_t* A0 = p.A0 + (long long)bz * p.sA;
+  const half_t* A1 = p.A1 ? p.A1 + (long long)bz * p.sA : nullptr;
+  const half_t* Wt = p.Wt + (long long)bz * p.sW;
+
+  const int lrow = lane >> 3;
+  const int cch = (lane & 7) ^ lrow;  // logical 16-B chunk this lane fetches (source-side swizzle)
+
+  // ---- per-thread source pointers -------------------------------------------------------
+  // 32-bit element offsets from the (wave-uniform) operand bases keep the loop's address state in
+  // one VGPR per row instead of a 64-bit pointer (all tensors on the path are < 2^32 elements).
+  unsigned a_off[A_PW];   // dense: row offset (same row index in both concat sources use their own pitch)
+  unsigned a_off1[A_PW];  // dense: row offset in the second source ; conv: current tap offset (~0u = zero tap)
+  int a_b[A_PW], a_iy[A_PW], a_ix[A_PW];
+#pragma unroll
+  for (int i = 0; i < A_PW; i++) {
+    const int row = (wave + i * NW) * 8 + lrow;
+    int m = m0 + row;
+    const bool ok = m < p.M;
+    if (!ok) m = p.M - 1;
+    if constexpr (!CONV) {
+      a_off[i] = (unsigned)m * (unsigned)p.lda0 + cch * 8;
+      a_off1[i] = (unsigned)m * (unsigned)p.lda1 + cch * 8;
+      a_b[i] = a_iy[i] = a_ix[i] = 0;
+    } else {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_b[i] = ok ? b : -1;
+      a_iy[i] = oy * p.stride - p.pad;
+      a_ix[i] = ox * p.stride - p.pad;
+      a_off[i] = 0;
+      a_off1[i] = ~0u;
+    }
+  }
+  unsigned w_off[W_PW];
+#pragma unroll
+  for (int i = 0; i < W_PW; i++) {
+    const int rho = (wave + i * NW) * 8 + lrow;  // LDS row of the W tile
+    const int wq = rho / BNw, rr = rho - wq * BNw, fn = rr >> 4, ii = rr & 15;
+    int n = n0 + wq * BNw + (ii >> 2) * (4 * FN) + fn * 4 + (ii & 3);  // column permutation
+    if (n >= p.N) n = p.N - 1;
+    w_off[i] = (unsigned)n * (unsigned)p.ldw + cch * 8;
+  }
+  const half_t* zsrc = p.zeros + cch * 8;
+
+  // conv: running (tap, channel-chunk) of the NEXT tile to stage
+  const int cpt = CONV ? (p.Cin >> 6) : 1;
+  int st_tap = 0, st_cc = 0;
+  auto conv_tap_ptrs = [&](int tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int Heff = p.ups ? 2 * p.Hs : p.Hs, Weff = p.ups ? 2 * p.Ws : p.Ws;
+#pragma unroll
+    for (int i = 0; i < A_PW; i++) {
+      const int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
+      const bool ok = a_b[i] >= 0 && (unsigned)iy < (unsigned)Heff && (unsigned)ix < (unsigned)Weff;
+      const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
+      a_off1[i] = ok ? (unsigned)((a_b[i] * p.Hs + sy) * p.Ws + sx) * (unsigned)p.lda0 + cch * 8 : ~0u;
+    }
+  };
+  if constexpr (CONV) conv_tap_ptrs(0);
+
+  auto stage = [&](int kt, int buf) {
+    char* sA = smem + buf * TILE_BYTES;
+    char* sW = sA + BM * 128;
+    const int k0 = kt * 64;
+    if constexpr (!CONV) {
+      if (k0 >= p.K0) {  // wave-uniform: second concat source
+        const half_t* base = A1 + (k0 - p.K0);
+#pragma unroll
+        for (int i = 0; i < A_PW; i++) {
+          const int j = wave + i * NW;
+          if (A_INSTR % NW == 0 || j < A_INSTR) glds16(base + a_off1[i], sA + j * 1024);
+        }
+      } else {
+        const half_t* base = A0 + k0;
+#pragma unroll
+        for (int i = 0; i < A_PW; i++) {
+          const int j = wave + i * NW;
+          if (A_INSTR % NW == 0 || j < A_INSTR) glds16(base + a_off[i], sA + j * 1024);
+        }
+      }
+    } else {
+      const half_t* base = A0 + st_cc * 64;
+#pragma unroll
+      for (int i = 0; i < A_PW; i++) {
+        const int j = wave + i * NW;
+        if (A_INSTR % NW == 0 || j < A_INSTR) {
+          const half_t* src = (a_off1[i] != ~0u) ? base + a_off1[i] : zsrc;
+          glds16(src, sA + j * 1024);
+        }
+      }
+      if (++st_cc == cpt) {
+        st_cc = 0;
+        ++st_tap;
+        if (st_tap < 9) conv_tap_ptrs(st_tap);
+      }
+    }
+    const half_t* wbase = Wt + k0;
+#pragma unroll
+    for (int i = 0; i < W_PW; i++) {
+      const int j = wave + i * NW;
+      if (W_INSTR % NW == 0 || j < W_INSTR) glds16(wbase + w_off[i], sW + j * 1024);
+    }
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int a = 0; a < FM; a++)
+#pragma unroll
+    for (int b = 0; b < FN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row R = base + (lane&15); chunk c = kk*4 + (lane>>4); phys = c ^ (R&7)
+  const int rsel = lane & 15, key = lane & 7, cq = lane >> 4;
+  const int a_rd = (wm * BMw + rsel) * 128, w_rd = (wn * BNw + rsel) * 128;
+
+  auto compute = [&](int buf) {
+    const char* sA = smem + buf * TILE_BYTES;
+    const char* sW = sA + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const int coff = ((kk * 4 + cq) ^ key) << 4;
+      h8 af[FM], wf[FN];
+#pragma unroll
+      for (int a = 0; a < FM; a++) af[a] = *(const h8*)(sA + a_rd + a * 2048 + coff);
+#pragma unroll
+      for (int b = 0; b < FN; b++) wf[b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
+#pragma unroll
+      for (int a = 0; a < FM; a++)
+#pragma unroll
+        for (int b = 0; b < FN; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[b], af[a], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  const int nk = p.K >> 6;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int g = lane >> 4;
+  const int epi = p.epi;
+  const int nb = n0 + wn * BNw + g * (4 * FN);
+#pragma unroll
+  for (int a = 0; a < FM; a++) {
+    const int m = m0 + wm * BMw + a * 16 + rsel;
+    if (m >= p.M) continue;
+    float v[4 * FN];
+#pragma unroll
+    for (int b = 0; b < FN; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[b * 4 + r] = acc[a][b][r] * p.out_scale;
+    if (epi & EPI_BIAS_M) {
+      const float bm = p.bias[m];
+#pragma unroll
+      for (int j = 0; j < 4 * FN; j++) v[j] += bm;
+    }
+    if (epi & EPI_BIAS_N) {
+#pragma unroll
+      for (int b = 0; b < FN; b++)
+        if (nb + b * 4 < p.N) {
+          const f4 bv = *(const f4*)(p.bias + nb + b * 4);
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+        }
+    }
+    if (epi & EPI_ROWVEC) {
+      const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.rowvec_ld;
+#pragma unroll
+      for (int b = 0; b < FN; b++)
+        if (nb + b * 4 < p.N) {
+          const f4 bv = *(const f4*)(rv + nb + b * 4);
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+        }
+    }
+    if (epi & EPI_RESIDUAL) {
+      long long rrow = m;
+      if (epi & EPI_RES_UPS) {
+        const int hw = p.Ho * p.Wo;
+        const int bb = m / hw, rem = m - bb * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        rrow = ((long long)bb * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+      }
+      const half_t* rp = p.R + (long long)bz * p.sR + rrow * p.ldr + nb;
+#pragma unroll
+      for (int b = 0; b < FN; b++)
+        if (nb + b * 4 < p.N) {
+          const h4 rvv = *(const h4*)(rp + b * 4);
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[b * 4 + r] += (float)rvv[r];
+        }
+    }
+    if (epi & EPI_GEGLU) {
+      half_t* cp = (half_t*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + (nb >> 1);
+#pragma unroll
+      for (int b = 0; b < FN; b++)
+        if (nb + b * 4 < p.N) {
+          h2 o;
+          o[0] = (half_t)(v[b * 4 + 0] * gelu_tanh_f(v[b * 4 + 1]));
+          o[1] = (half_t)(v[b * 4 + 2] * gelu_tanh_f(v[b * 4 + 3]));
+          *(h2*)(cp + b * 2) = o;
+        }
+    } else if (epi & EPI_OUT_F32) {
+      float* cp = (float*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + nb;
+#pragma unroll
+      for (int b = 0; b < FN; b++)
+        if (nb + b * 4 < p.N) *(f4*)(cp + b * 4) = f4{v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]};
+    } else {
+      half_t* cp = (half_t*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + nb;
+#pragma unroll
+      for (int b = 0; b < FN; b++)
+        if (nb + b * 4 < p.N) {
+          h4 o;
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[r] = (half_t)v[b * 4 + r];
+          *(h4*)(cp + b * 4) = o;
+        }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+template <int WGM, int WGN, int FM, int FN, bool CONV>
+static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
+  constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  GemmK kk = k;
+  kk.tiles_n = ceil_div(k.N, BN);
+  const int tiles_m = ceil_div(k.M, BM);
+  dim3 grid(tiles_m * kk.tiles_n, batch);
+  hipLaunchKernelGGL(fn, grid, dim3(WGM * WGN * 64), LDS, ctx->stream, kk);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+template <bool CONV>
+static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
+  const int M = k.M, N = k.N;
+  if (N <= 16) return launch_cfg<4, 1, 2, 1, CONV>(ctx, k, batch);
+  const bool n160 = (N % 160 == 0);
+  const int BN = n160 ? 160 : 128;
+  // prefer 128-row tiles when they still give every CU at least one tile
+  const long long tiles128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
+  const bool big = tiles128 >= 256;
+  if (n160) return big ? launch_cfg<2, 2, 4, 5, CONV>(ctx, k, batch) : launch_cfg<2, 2, 2, 5, CONV>(ctx, k, batch);
+  return big ? launch_cfg<2, 2, 4, 4, CONV>(ctx, k, batch) : launch_cfg<2, 2, 2, 4, CONV>(ctx, k, batch);
+}
+
+int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) TSD_FAIL(TSD_E_SHAPE, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.K % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: K=%d must be a multiple of 64 (pad at pack time)", a.K);
+  if (a.N % 4) TSD_FAIL(TSD_E_SHAPE, "gemm: N=%d must be a multiple of 4", a.N);
+  if ((a.epi & EPI_GEGLU) && (a.N % 8)) TSD_FAIL(TSD_E_SHAPE, "gemm: GEGLU needs N %% 8 == 0");
+  if (a.conv) {
+    if (a.Cin % 64 || a.K != 9 * a.Cin) TSD_FAIL(TSD_E_SHAPE, "conv3x3: Cin=%d K=%d", a.Cin, a.K);
+    if (a.batch != 1) TSD_FAIL(TSD_E_ARG, "conv3x3: batch is folded into M");
+  } else {
+    if (a.K0 % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: concat split K0=%d must be a multiple of 64", a.K0);
+  }
+  if (!ctx->launch()) return TSD_OK;
+  GemmK k;
+  k.A0 = a.A0; k.A1 = a.A1; k.Wt = a.Wt; k.R = a.R; k.zeros = ctx->zeros;
+  k.bias = a.bias; k.rowvec = a.rowvec; k.C = a.C;
+  k.sA = a.sA; k.sW = a.sW; k.sC = a.sC; k.sR = a.sR;
+  k.lda0 = a.lda0; k.lda1 = a.lda1; k.K0 = (a.A1 ? a.K0 : a.K); k.ldw = a.ldw; k.ldr = a.ldr; k.ldc = a.ldc;
+  k.rowvec_ld = a.rowvec_ld; k.rows_per_batch = a.rows_per_batch > 0 ? a.rows_per_batch : 1;
+  k.M = a.M; k.N = a.N; k.K = a.K;
+  k.Hs = a.Hs; k.Ws = a.Ws; k.Ho = a.Ho; k.Wo = a.Wo; k.Cin = a.Cin; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
+  k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
+  return a.conv ? dispatch<true>(ctx, k, a.batch) : dispatch<false>(ctx, k, a.batch);
+}

@@ -1,0 +1,245 @@
+// kernels_norm.hip - GroupNorm (+SiLU) and LayerNorm on NHWC fp16 activations (HBM-bound).
+//
+// Replaces `GroupNorm.forward` helpers/utils.mojo:1845-1885 (+ `sum/mean/std` :1360-1380),
+// `SiLU.forward` :1892-1902 when fused, and `LayerNorm` :2052-2061 (build semantics App.A D8).
+// Formula kept literal (App.A D12): y = (x - mu) / (sigma + eps) * gamma, population sigma,
+// eps added to sigma, scalar gamma, no beta.
+//
+// GroupNorm is two launches: per-slab partial (sum, sumsq) over full NHWC pixel rows (coalesced
+// 16-B loads, fp32 accumulation, deterministic - no atomics), then an apply pass that finishes
+// the statistics in double and streams the tensor once.  The source may be the channel-concat
+// of two tensors (UNet skip connections, diffusion.mojo:253-270) so the concat is never
+// materialised for the normalised branch.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int GN_MAX_CPT = 2;  // chunks (of 8 channels) per thread: C <= 4096
+
+struct GnK {
+  const half_t* x0; const half_t* x1;
+  int ld0, ld1, C0, C, HW, G, cpg;
+  int nslab, slab_pixels;
+  float* partial;  // [B][nslab][G][2]
+  float eps, gamma;
+  int silu;
+  half_t* y; int ldy;
+  int apply_pixels;
+};
+
+__device__ __forceinline__ h8 gn_load(const GnK& p, int64_t pixg, int ch) {
+  const int c = ch * 8;
+  if (c < p.C0) return *(const h8*)(p.x0 + pixg * p.ld0 + c);
+  return *(const h8*)(p.x1 + pixg * p.ld1 + (c - p.C0));
+}
+
+__global__ __launch_bounds__(256) void k_gn_partial(const GnK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gn[];
+  float* s1 = (float*)smem_gn;  // [C]
+  float* s2 = s1 + p.C;
+  const int tid = threadIdx.x;
+  const int nch = p.C >> 3;
+  const int b = blockIdx.y, slab = blockIdx.x;
+  for (int i = tid; i < 2 * p.C; i += 256) s1[i] = 0.f;
+  __syncthreads();
+  const int PL = nch <= 256 ? 256 / nch : 1;     // pixel lanes
+  const int pl = nch <= 256 ? tid / nch : 0;
+  const int ch0 = nch <= 256 ? tid % nch : tid;
+  const bool active = nch <= 256 ? (tid < PL * nch) : true;
+  float a1[GN_MAX_CPT][8], a2[GN_MAX_CPT][8];
+#pragma unroll
+  for (int q = 0; q < GN_MAX_CPT; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) a1[q][j] = a2[q][j] = 0.f;
+  const int p_begin = slab * p.slab_pixels;
+  const int p_end = min(p.HW, p_begin + p.slab_pixels);
+  if (active) {
+    for (int pix = p_begin + pl; pix < p_end; pix += PL) {
+      const int64_t pixg = (int64_t)b * p.HW + pix;
+#pragma unroll
+      for (int q = 0; q < GN_MAX_CPT; q++) {
+        const int ch = ch0 + q * 256;
+        if (ch < nch) {
+          const h8 v = gn_load(p, pixg, ch);
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float f = (float)v[j];
+            a1[q][j] += f;
+            a2[q][j] += f * f;
+          }
+        }
+      }
+    }
+    // combine pixel lanes: serialise over pl so the sum order is fixed (deterministic)
+  }
+  for (int turn = 0; turn < PL; turn++) {
+    if (active && pl == turn) {
+#pragma unroll
+      for (int q = 0; q < GN_MAX_CPT; q++) {
+        const int ch = ch0 + q * 256;
+        if (ch < nch) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            s1[ch * 8 + j] += a1[q][j];
+            s2[ch * 8 + j] += a2[q][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int g = tid; g < p.G; g += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = g * p.cpg; c < (g + 1) * p.cpg; c++) {
+      t1 += s1[c];
+      t2 += s2[c];
+    }
+    float* o = p.partial + (((int64_t)b * p.nslab + slab) * p.G + g) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gn[];
+  float* mean = (float*)smem_gn;  // [G]
+  float* rinv = mean + p.G;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  for (int g = tid; g < p.G; g += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int s = 0; s < p.nslab; s++) {
+      const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
+      t1 += (double)o[0];
+      t2 += (double)o[1];
+    }
+    const double n = (double)p.cpg * (double)p.HW;
+    const double mu = t1 / n;
+    double var = t2 / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[g] = (float)mu;
+    rinv[g] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));
+  }
+  __syncthreads();
+  const int nch = p.C >> 3;
+  const int PL = nch <= 256 ? 256 / nch : 1;
+  const int pl = nch <= 256 ? tid / nch : 0;
+  const int ch0 = nch <= 256 ? tid % nch : tid;
+  if (nch <= 256 && tid >= PL * nch) return;
+  float mu[GN_MAX_CPT][8], ri[GN_MAX_CPT][8];
+#pragma unroll
+  for (int q = 0; q < GN_MAX_CPT; q++) {
+    const int ch = ch0 + q * 256;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int g = ch < nch ? (ch * 8 + j) / p.cpg : 0;
+      mu[q][j] = mean[g];
+      ri[q][j] = rinv[g];
+    }
+  }
+  const int p_begin = blockIdx.x * p.apply_pixels;
+  const int p_end = min(p.HW, p_begin + p.apply_pixels);
+  for (int pix = p_begin + pl; pix < p_end; pix += PL) {
+    const int64_t pixg = (int64_t)b * p.HW + pix;
+#pragma unroll
+    for (int q = 0; q < GN_MAX_CPT; q++) {
+      const int ch = ch0 + q * 256;
+      if (ch < nch) {
+        const h8 v = gn_load(p, pixg, ch);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          float f = ((float)v[j] - mu[q][j]) * ri[q][j];
+          if (p.silu) f = f / (1.f + __expf(-f));
+          o[j] = (half_t)f;
+        }
+        *(h8*)(p.y + pixg * p.ldy + ch * 8) = o;
+      }
+    }
+  }
+}
+
+int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
+                     int silu, half_t* y, int ldy) {
+  if (C % 8 || C % groups || C > 256 * 8 * GN_MAX_CPT)
+    TSD_FAIL(TSD_E_SHAPE, "groupnorm: C=%d groups=%d unsupported", C, groups);
+  const int C0 = src.x1 ? src.C0 : C;
+  if (C0 % 8 || src.ld0 % 8 || (src.x1 && src.ld1 % 8) || ldy % 8) TSD_FAIL(TSD_E_SHAPE, "groupnorm: pitches must be multiples of 8");
+  GnK k;
+  k.x0 = src.x0; k.x1 = src.x1; k.ld0 = src.ld0; k.ld1 = src.ld1; k.C0 = C0; k.C = C; k.HW = HW; k.G = groups;
+  k.cpg = C / groups;
+  k.nslab = std::max(1, std::min(64, HW / 64));
+  k.slab_pixels = ceil_div(HW, k.nslab);
+  k.nslab = ceil_div(HW, k.slab_pixels);
+  k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
+  if (!k.partial) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
+  k.eps = eps; k.gamma = gamma; k.silu = silu; k.y = y; k.ldy = ldy;
+  k.apply_pixels = 64;
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)2 * C * sizeof(float), ctx->stream, k);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
+                     ctx->stream, k);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- LayerNorm over the last dim of (rows, C): one wave per row, data held in registers ----
+constexpr int LN_MAX_CH = 4;  // C <= 2048
+__global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x, int64_t rows, int C, int ldx, float eps,
+                                                   half_t* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C >> 3;
+  const half_t* xr = x + row * ldx;
+  h8 v[LN_MAX_CH];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_MAX_CH; q++) {
+    const int ch = lane + q * 64;
+    if (ch < nch) {
+      v[q] = *(const h8*)(xr + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += (float)v[q][j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_MAX_CH; q++) {
+    const int ch = lane + q * 64;
+    if (ch < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float d = (float)v[q][j] - mu;
+        ss += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float r = 1.f / (sqrtf(ss / (float)C) + eps);
+  half_t* yr = y + row * ldy;
+#pragma unroll
+  for (int q = 0; q < LN_MAX_CH; q++) {
+    const int ch = lane + q * 64;
+    if (ch < nch) {
+      h8 o;
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = (half_t)(((float)v[q][j] - mu) * r);
+      *(h8*)(yr + ch * 8) = o;
+    }
+  }
+}
+
+int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy) {
+  if (C % 8 || C > 64 * 8 * LN_MAX_CH) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d unsupported", C);
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps, y,
+                     ldy);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}

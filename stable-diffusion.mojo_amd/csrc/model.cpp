@@ -1,0 +1,231 @@
+// model.cpp - device-resident packed weights: one blob per model (what RCCL broadcasts),
+// per-parameter upload/pack, synthetic counter-RNG init, and the resolved weight trees.
+#include <string.h>
+
+#include "model.h"
+
+static size_t packed_bytes(const ParamSpec& p) {
+  if (!p.used) return 0;
+  switch (p.kind) {
+    case P_CONV_W: return (size_t)p.Opad * p.shape[2] * p.shape[3] * p.Kpad * sizeof(half_t);
+    case P_CONV_B: return (size_t)p.Opad * sizeof(float);
+    case P_LIN_W: return (size_t)p.shape[0] * p.Kpad * sizeof(half_t);
+    default: return (size_t)p.shape[0] * sizeof(float);
+  }
+}
+
+extern "C" int tsd_model_create(tsd_ctx* ctx, int kind, tsd_model** out) {
+  if (!ctx || !out) TSD_FAIL(TSD_E_ARG, "tsd_model_create: NULL argument");
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_ENCODER) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
+  tsd_model* m = new tsd_model();
+  m->ctx = ctx;
+  m->kind = kind;
+  m->params = build_param_specs(kind);
+  // blob layout: time-projection weights (region 1) and biases (region 2) are laid out contiguously in
+  // layer order so the nine Linear(1280,C) become ONE [6720][1280] GEMV (SURVEY.md App.D K8).
+  size_t off = 0;
+  for (auto& p : m->params) p.bytes = packed_bytes(p);
+  {  // regions 1/2 densely packed (no gaps between the nine tensors), everything else 256-B aligned
+    size_t o = 0;
+    for (auto& p : m->params) if (p.region == 1) { p.off = o; o += p.bytes; }
+    o = (o + 255) & ~size_t(255);
+    for (auto& p : m->params) if (p.region == 2) { p.off = o; o += p.bytes; }
+    o = (o + 255) & ~size_t(255);
+    for (auto& p : m->params) if (p.region == 0) { p.off = o; o += p.bytes; o = (o + 255) & ~size_t(255); }
+    off = o;
+  }
+  m->blob_bytes = off;
+  for (size_t i = 0; i < m->params.size(); i++) m->index[m->params[i].name] = (int)i;
+  m->loaded.assign(m->params.size(), 0);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc((void**)&m->blob, m->blob_bytes);
+  if (e != hipSuccess) {
+    delete m;
+    TSD_FAIL(TSD_E_ALLOC, "weights: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+  }
+  HIP_TRY(hipMemsetAsync(m->blob, 0, m->blob_bytes, ctx->stream));
+  TSD_TRY(model_resolve(m));
+  *out = m;
+  return TSD_OK;
+}
+
+extern "C" int tsd_model_destroy(tsd_model* m) {
+  if (!m) return TSD_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  if (m->blob) hipFree(m->blob);
+  delete m;
+  return TSD_OK;
+}
+
+// pack parameter `i` from a device fp32 tensor in the reference layout
+static int pack_param(tsd_model* m, int i, const float* dev_src) {
+  tsd_ctx* ctx = m->ctx;
+  const ParamSpec& p = m->params[i];
+  if (!p.used) return TSD_OK;
+  char* dst = m->blob + p.off;
+  switch (p.kind) {
+    case P_CONV_W:
+      return launch_pack_conv(ctx, dev_src, (int)p.shape[0], (int)p.shape[1], (int)p.shape[2], (half_t*)dst, p.Opad,
+                              p.Kpad);
+    case P_CONV_B: return launch_pack_bias(ctx, dev_src, (int)p.shape[0], (float*)dst, p.Opad, 0);
+    case P_LIN_W:
+      return launch_pack_linear(ctx, dev_src, (int)p.shape[0], (int)p.shape[1], (half_t*)dst, p.Kpad, p.interleave);
+    default: return launch_pack_bias(ctx, dev_src, (int)p.shape[0], (float*)dst, (int)p.shape[0], p.interleave);
+  }
+}
+
+extern "C" int tsd_model_set_param(tsd_model* m, int index, const float* data, int64_t numel) {
+  if (!m || !data) TSD_FAIL(TSD_E_ARG, "tsd_model_set_param: NULL argument");
+  if (index < 0 || index >= (int)m->params.size()) TSD_FAIL(TSD_E_ARG, "param index %d out of range", index);
+  const ParamSpec& p = m->params[index];
+  if (numel != p.numel())
+    TSD_FAIL(TSD_E_SHAPE, "param %s: got %lld elements, expected %lld", p.name.c_str(), (long long)numel,
+             (long long)p.numel());
+  m->loaded[index] = 1;
+  if (!p.used) return TSD_OK;  // allocated by the reference, never read by its forward
+  tsd_ctx* ctx = m->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  TSD_TRY(ctx_reserve_staging(ctx, (size_t)numel * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(ctx->staging, data, (size_t)numel * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  TSD_TRY(pack_param(m, index, (const float*)ctx->staging));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  m->ready = false;
+  return TSD_OK;
+}
+
+extern "C" int tsd_model_init_random(tsd_model* m, uint64_t seed) {
+  if (!m) TSD_FAIL(TSD_E_ARG, "tsd_model_init_random: NULL model");
+  tsd_ctx* ctx = m->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int64_t maxn = 0;
+  for (auto& p : m->params) if (p.used) maxn = std::max(maxn, p.numel());
+  TSD_TRY(ctx_reserve_staging(ctx, (size_t)maxn * sizeof(float)));
+  for (size_t i = 0; i < m->params.size(); i++) {
+    const ParamSpec& p = m->params[i];
+    m->loaded[i] = 1;
+    if (!p.used) continue;
+    float* tmp = (float*)ctx->staging;
+    if (p.bound == 0.f) HIP_TRY(hipMemsetAsync(tmp, 0, (size_t)p.numel() * sizeof(float), ctx->stream));
+    else TSD_TRY(launch_fill_uniform(ctx, tmp, p.numel(), seed, (uint64_t)m->kind * 4096 + i, p.bound));
+    TSD_TRY(pack_param(m, (int)i, tmp));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  m->ready = false;
+  return TSD_OK;
+}
+
+extern "C" int tsd_model_packed_blob(tsd_model* m, void** device_ptr, size_t* bytes) {
+  if (!m || !device_ptr || !bytes) TSD_FAIL(TSD_E_ARG, "tsd_model_packed_blob: NULL argument");
+  *device_ptr = m->blob;
+  *bytes = m->blob_bytes;
+  return TSD_OK;
+}
+
+extern "C" int tsd_model_mark_loaded(tsd_model* m) {
+  if (!m) TSD_FAIL(TSD_E_ARG, "NULL model");
+  std::fill(m->loaded.begin(), m->loaded.end(), 1);
+  m->ready = false;
+  return TSD_OK;
+}
+
+int model_check_ready(tsd_model* m) {
+  if (m->ready) return TSD_OK;
+  for (size_t i = 0; i < m->params.size(); i++)
+    if (m->params[i].used && !m->loaded[i])
+      TSD_FAIL(TSD_E_STATE, "model parameter %s was never set", m->params[i].name.c_str());
+  m->ready = true;
+  return TSD_OK;
+}
+
+ConvW model_conv(const tsd_model* m, const std::string& prefix) {
+  ConvW w;
+  auto it = m->index.find(prefix + ".kernel");
+  if (it == m->index.end()) return w;
+  const ParamSpec& pw = m->params[it->second];
+  const ParamSpec& pb = m->params[it->second + 1];
+  if (!pw.used) return w;
+  w.w = (const half_t*)(m->blob + pw.off);
+  w.b = (const float*)(m->blob + pb.off);
+  w.O = (int)pw.shape[0]; w.I = (int)pw.shape[1]; w.k = (int)pw.shape[2]; w.Ipad = pw.Kpad; w.Opad = pw.Opad;
+  return w;
+}
+
+LinW model_lin(const tsd_model* m, const std::string& prefix, bool use_bias) {
+  LinW w;
+  auto it = m->index.find(prefix + ".weight");
+  if (it == m->index.end()) return w;
+  const ParamSpec& pw = m->params[it->second];
+  const ParamSpec& pb = m->params[it->second + 1];
+  w.w = (const half_t*)(m->blob + pw.off);
+  w.b = (use_bias && pb.used) ? (const float*)(m->blob + pb.off) : nullptr;
+  w.N = (int)pw.shape[0]; w.K = (int)pw.shape[1]; w.Kpad = pw.Kpad;
+  return w;
+}
+
+int model_resolve(tsd_model* m) {
+  if (m->kind == TSD_MODEL_DIFFUSION) {
+    UNetW& u = m->unet;
+    u.t1 = model_lin(m, "time_embed.layer1", true);
+    u.t2 = model_lin(m, "time_embed.layer2", true);
+    int toff = 0;
+    bool first = true;
+    for (int i = 0; i < 23; i++) {
+      const LayerDef& l = UNET_LAYERS[i];
+      const std::string n = "unet.layer" + std::to_string(i + 1);
+      if (l.kind == L_RES) {
+        ResW& r = u.res[i];
+        r.cin = l.a; r.cout = l.b; r.groups = 32; r.has_skip = l.a != l.b;
+        r.conv1 = model_conv(m, n + ".layer2");
+        r.conv2 = model_conv(m, n + ".layer5");
+        if (r.has_skip) r.skip = model_conv(m, n + ".layer6");
+        r.time = model_lin(m, n + ".layer3", true);
+        r.time_off = toff;
+        if (first) { u.tproj = r.time; first = false; }
+        toff += l.b;
+      } else if (l.kind == L_ATTN) {
+        AttnW& a = u.attn[i];
+        a.n_head = l.a; a.n_embed = l.b; a.C = l.a * l.b;
+        a.conv_in = model_conv(m, n + ".layer2");
+        a.sa_in = model_lin(m, n + ".layer4.in_proj", false);
+        a.sa_out = model_lin(m, n + ".layer4.out_proj", true);
+        a.ca_q = model_lin(m, n + ".layer6.q_proj", false);
+        a.ca_k = model_lin(m, n + ".layer6.k_proj", false);
+        a.ca_v = model_lin(m, n + ".layer6.v_proj", false);
+        a.ca_out = model_lin(m, n + ".layer6.out_proj", true);
+        a.geglu1 = model_lin(m, n + ".layer8", true);
+        a.geglu2 = model_lin(m, n + ".layer9", true);
+        a.conv_out = model_conv(m, n + ".layer10");
+      }
+    }
+    u.tproj.N = toff;  // 6720 rows: the nine layer3 weights are contiguous in the blob
+    u.conv1 = model_conv(m, "unet.layer1");
+    u.conv4 = model_conv(m, "unet.layer4");
+    u.conv7 = model_conv(m, "unet.layer7");
+    u.final_conv = model_conv(m, "final.layer2");
+  } else {
+    const LayerDef* L = m->kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
+    const int n_layers = m->kind == TSD_MODEL_DECODER ? 26 : 19;
+    VaeW& v = m->vae;
+    v.conv.assign(n_layers, ConvW());
+    v.res.assign(n_layers, ResW());
+    v.attn.assign(n_layers, VaeAttnW());
+    for (int i = 0; i < n_layers; i++) {
+      const LayerDef& l = L[i];
+      const std::string n = "l" + std::to_string(i + 1);
+      if (l.kind == L_CONV || l.kind == L_CONV_S2) v.conv[i] = model_conv(m, n);
+      else if (l.kind == L_RES) {
+        ResW& r = v.res[i];
+        r.cin = l.a; r.cout = l.b; r.groups = 16; r.has_skip = l.a != l.b;  // GroupNorm(16), vae.mojo:42-43
+        r.conv1 = model_conv(m, n + ".conv1");
+        r.conv2 = model_conv(m, n + ".conv2");
+        if (r.has_skip) r.skip = model_conv(m, n + ".res_conv_layer");
+      } else if (l.kind == L_ATTN) {
+        v.attn[i].C = l.a;
+        v.attn[i].in_proj = model_lin(m, n + ".attention.in_proj", true);
+        v.attn[i].out_proj = model_lin(m, n + ".attention.out_proj", true);
+      }
+    }
+  }
+  return TSD_OK;
+}

@@ -1,0 +1,88 @@
+// model.h - parameter inventory, packed device weights and resolved weight trees.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+enum ParamKind { P_CONV_W = 0, P_CONV_B = 1, P_LIN_W = 2, P_LIN_B = 3 };
+
+struct ParamSpec {
+  std::string name;
+  int64_t shape[4] = {0, 0, 0, 0};
+  int ndim = 0;
+  int kind = 0;
+  bool used = true;
+  float bound = 0.f;  // synthetic-init bound (0 -> zeros)
+  // packing
+  int Opad = 0, Kpad = 0;  // conv: Opad rows, Kpad = Ipad ; linear: Kpad
+  int interleave = 0;      // GEGLU (a,g) row interleave (diffusion.mojo:138-141)
+  int region = 0;          // 0 normal, 1 time-projection weights, 2 time-projection biases (kept contiguous)
+  size_t off = 0, bytes = 0;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < ndim; i++) n *= shape[i];
+    return n;
+  }
+};
+
+// layer tables (diffusion.mojo:177-201, vae.mojo:94-112,194-219)
+enum LayerKind { L_CONV, L_CONV_S2, L_RES, L_ATTN, L_UP, L_GN, L_SILU };
+struct LayerDef { int kind; int a, b, c, d; };
+extern const LayerDef UNET_LAYERS[23];
+extern const LayerDef DECODER_LAYERS[26];
+extern const LayerDef ENCODER_LAYERS[19];
+
+std::vector<ParamSpec> build_param_specs(int model_kind);
+
+struct ResW {
+  ConvW conv1, conv2, skip;
+  LinW time;       // UNet only (kept for the op-level path; the model path uses the concatenated table)
+  int cin = 0, cout = 0, groups = 32;
+  bool has_skip = false;
+  int time_off = 0;  // column offset into the concatenated time projection [B][6720]
+};
+struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
+  int n_head = 0, n_embed = 0, C = 0, d_ctx = 768;
+  ConvW conv_in, conv_out;
+  LinW sa_in, sa_out, ca_q, ca_k, ca_v, ca_out, geglu1, geglu2;
+};
+struct VaeAttnW {  // vae.mojo:9-11
+  int C = 0;
+  LinW in_proj, out_proj;
+};
+
+struct UNetW {
+  LinW t1, t2;       // Time_Embedding
+  LinW tproj;        // concatenated layer3 of the 9 residual blocks: [6720][1280]
+  ConvW conv1, conv4, conv7, final_conv;
+  ResW res[23];
+  AttnW attn[23];
+};
+struct VaeW {
+  std::vector<ConvW> conv;      // indexed by layer (1-based position - 1)
+  std::vector<ResW> res;
+  std::vector<VaeAttnW> attn;
+};
+
+struct PlanKey { int B, L, T; bool operator<(const PlanKey& o) const { return B != o.B ? B < o.B : (L != o.L ? L < o.L : T < o.T); } };
+
+struct tsd_model {
+  tsd_ctx* ctx = nullptr;
+  int kind = 0;
+  std::vector<ParamSpec> params;
+  std::map<std::string, int> index;
+  char* blob = nullptr;
+  size_t blob_bytes = 0;
+  std::vector<char> loaded;
+  bool ready = false;
+  UNetW unet;
+  VaeW vae;
+  std::map<PlanKey, size_t> plans;  // workspace high-water mark per problem shape
+};
+
+int model_resolve(tsd_model* m);                      // fill unet / vae from the packed blob
+ConvW model_conv(const tsd_model* m, const std::string& prefix);
+LinW model_lin(const tsd_model* m, const std::string& prefix, bool use_bias);
+int model_check_ready(tsd_model* m);

@@ -1,0 +1,108 @@
+// runtime.cpp - context, error string, workspace arena, staging.  No CPU fallback anywhere: if HIP
+// reports no device every compute entry point fails with TSD_E_HIP.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void tsd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int tsd_version(void) { return TSD_VERSION; }
+extern "C" const char* tsd_last_error(void) { return g_err; }
+
+extern "C" int tsd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int tsd_ctx_create(int device, tsd_ctx** out) {
+  if (!out) TSD_FAIL(TSD_E_ARG, "tsd_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    TSD_FAIL(TSD_E_HIP, "tsd_ctx_create: no HIP device visible (libtsd has no CPU fallback)");
+  if (device < 0 || device >= n) TSD_FAIL(TSD_E_ARG, "tsd_ctx_create: device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    TSD_FAIL(TSD_E_HIP, "tsd_ctx_create: device %d is %s; libtsd is built for gfx950 only", device, prop.gcnArchName);
+  tsd_ctx* c = new tsd_ctx();
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc((void**)&c->zeros, 4096));
+  HIP_TRY(hipMemsetAsync(c->zeros, 0, 4096, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return TSD_OK;
+}
+
+extern "C" int tsd_ctx_destroy(tsd_ctx* c) {
+  if (!c) return TSD_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->arena.base) hipFree(c->arena.base);
+  if (c->staging) hipFree(c->staging);
+  if (c->zeros) hipFree(c->zeros);
+  hipEventDestroy(c->ev0);
+  hipEventDestroy(c->ev1);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return TSD_OK;
+}
+
+extern "C" int tsd_ctx_synchronize(tsd_ctx* c) {
+  if (!c) TSD_FAIL(TSD_E_ARG, "tsd_ctx_synchronize: ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TSD_OK;
+}
+
+extern "C" int tsd_ctx_timer_start(tsd_ctx* c) {
+  if (!c) TSD_FAIL(TSD_E_ARG, "ctx is NULL");
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return TSD_OK;
+}
+extern "C" int tsd_ctx_timer_stop(tsd_ctx* c, float* ms) {
+  if (!c || !ms) TSD_FAIL(TSD_E_ARG, "ctx/ms is NULL");
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return TSD_OK;
+}
+
+int ctx_reserve_arena(tsd_ctx* c, size_t bytes) {
+  if (c->arena.cap >= bytes) return TSD_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->arena.base) HIP_TRY(hipFree(c->arena.base));
+  c->arena.base = nullptr;
+  c->arena.cap = 0;
+  const size_t want = bytes + (bytes >> 4) + (1 << 20);
+  hipError_t e = hipMalloc((void**)&c->arena.base, want);
+  if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "workspace arena: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  c->arena.cap = want;
+  return TSD_OK;
+}
+
+int ctx_reserve_staging(tsd_ctx* c, size_t bytes) {
+  if (c->staging_cap >= bytes) return TSD_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->staging) HIP_TRY(hipFree(c->staging));
+  c->staging = nullptr;
+  c->staging_cap = 0;
+  hipError_t e = hipMalloc(&c->staging, bytes);
+  if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "staging: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  c->staging_cap = bytes;
+  return TSD_OK;
+}
