@@ -62,6 +62,11 @@ int tsd_ctx_synchronize(tsd_ctx* ctx);
 /* hipEvent timing on the context's own stream (bench.py: torch.cuda.Event would not see it). */
 int tsd_ctx_timer_start(tsd_ctx* ctx);
 int tsd_ctx_timer_stop(tsd_ctx* ctx, float* elapsed_ms);
+/* Per-kernel-class timing with hipEvent pairs around every launch on the context stream (profiling pass
+ * only - adds one event pair per launch).  Classes: 0 dense GEMM, 1 conv3x3 implicit GEMM, 2 flash attention,
+ * 3 GroupNorm, 4 LayerNorm, 5 tiny-M linear, 6 elementwise/layout, 7 row softmax.  nclass <= 8. */
+int tsd_ctx_profile_begin(tsd_ctx* ctx);
+int tsd_ctx_profile_end(tsd_ctx* ctx, float* ms_per_class, int* launches_per_class, int nclass);
 
 /* ---- op level: one export per reference op struct (host fp32 in/out) ------------------ */
 

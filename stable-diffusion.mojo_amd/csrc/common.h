@@ -59,6 +59,35 @@ struct tsd_ctx {
   void* rccl_lib = nullptr;
   int nranks = 1, rank = 0;
   bool launch() const { return !arena.planning; }
+  // built-in per-kernel-class timer (hipEvents on THIS stream; bench.py's roofline leg)
+  bool profile = false;
+  std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
+  std::vector<int> prof_cls;
+  size_t prof_n = 0;
+};
+
+enum KernelClass : int {
+  KC_GEMM = 0, KC_CONV = 1, KC_ATTN = 2, KC_GROUPNORM = 3, KC_LAYERNORM = 4, KC_SMALL_LINEAR = 5,
+  KC_ELEMENTWISE = 6, KC_SOFTMAX = 7, KC_COUNT = 8
+};
+// RAII: records a start/stop event pair around the launches in its scope when profiling is on
+struct ProfScope {
+  tsd_ctx* c; bool on;
+  ProfScope(tsd_ctx* ctx, int cls) : c(ctx), on(ctx->profile && ctx->launch()) {
+    if (!on) return;
+    if (c->prof_n * 2 + 2 > c->prof_ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      c->prof_ev.push_back(a); c->prof_ev.push_back(b);
+    }
+    if (c->prof_cls.size() <= c->prof_n) c->prof_cls.push_back(cls); else c->prof_cls[c->prof_n] = cls;
+    (void)hipEventRecord(c->prof_ev[c->prof_n * 2], c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(c->prof_ev[c->prof_n * 2 + 1], c->stream);
+    c->prof_n++;
+  }
 };
 
 int ctx_reserve_arena(tsd_ctx* ctx, size_t bytes);

@@ -247,6 +247,7 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4) TSD_FAIL(TSD_E_SHAPE, "flash attention: misaligned pitches");
   if (a.Sq <= 0 || a.Sk <= 0) TSD_FAIL(TSD_E_SHAPE, "flash attention: empty sequence");
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_ATTN);
   AttnK k;
   k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros;
   k.sQ = a.sQ; k.sK = a.sK; k.sVt = a.sVt; k.sO = a.sO;

@@ -38,6 +38,7 @@ int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int
   if (Cdst % 8) TSD_FAIL(TSD_E_SHAPE, "nhwc channel pitch %d not a multiple of 8", Cdst);
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = (int64_t)B * H * W * (Cdst / 8);
+  ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_chw_to_nhwc, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, Cuse, scale, dst,
                      Cdst, total);
   HIP_TRY(hipGetLastError());
@@ -58,6 +59,7 @@ __global__ void k_nhwc_to_chw(const T* __restrict__ src, int C, int HW, int ld, 
 int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst) {
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = (int64_t)B * C * H * W;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_nhwc_to_chw<half_t>, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, ld, dst,
                      total);
   HIP_TRY(hipGetLastError());
@@ -66,6 +68,7 @@ int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, in
 int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int ld, float* dst) {
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = (int64_t)B * C * H * W;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_nhwc_to_chw<float>, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, ld, dst,
                      total);
   HIP_TRY(hipGetLastError());
@@ -85,6 +88,7 @@ int launch_f32_to_f16_rows(tsd_ctx* ctx, const float* src, int64_t rows, int col
                            int64_t rows_dst) {
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = rows_dst * ld_dst;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_f32_to_f16_rows, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, rows, cols, dst, ld_dst,
                      total);
   HIP_TRY(hipGetLastError());
@@ -204,6 +208,7 @@ int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols
 }
 int launch_softmax_rows_f16(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld) {
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_SOFTMAX);
   hipLaunchKernelGGL(k_softmax_rows<half_t>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const half_t*)x, cols,
                      ld, x, ld);
   HIP_TRY(hipGetLastError());
@@ -221,6 +226,7 @@ __global__ void k_time_embedding(const float* __restrict__ t, float t_scalar, fl
 }
 int launch_time_embedding(tsd_ctx* ctx, const float* t, float t_scalar, int B, float* out) {
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_time_embedding, dim3(B), dim3(192), 0, ctx->stream, t, t_scalar, out);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
@@ -276,6 +282,7 @@ int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, con
   if (B > SL_MAXB) TSD_FAIL(TSD_E_SHAPE, "small_linear: B=%d > %d", B, SL_MAXB);
   if (K % 8) TSD_FAIL(TSD_E_SHAPE, "small_linear: K=%d not a multiple of 8", K);
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_SMALL_LINEAR);
   const size_t lds = (size_t)B * K * sizeof(float);
   static bool attr = false;
   if (!attr) {
@@ -385,6 +392,7 @@ __global__ void k_ddpm_step(float* __restrict__ x, const float* __restrict__ eps
 int launch_ddpm_step(tsd_ctx* ctx, float* latents, const float* eps, const float* eps_uncond, float cfg_scale,
                      const float* noise, int64_t n, float sa, float sb, float c_x0, float c_xt, float sigma) {
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_ddpm_step, GRID1D(n, 256), dim3(256), 0, ctx->stream, latents, eps, eps_uncond, cfg_scale,
                      noise, n, sa, sb, c_x0, c_xt, sigma);
   HIP_TRY(hipGetLastError());

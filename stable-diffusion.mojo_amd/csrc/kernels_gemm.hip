@@ -345,6 +345,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     if (a.K0 % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: concat split K0=%d must be a multiple of 64", a.K0);
   }
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, a.conv ? KC_CONV : KC_GEMM);
   GemmK k;
   k.A0 = a.A0; k.A1 = a.A1; k.Wt = a.Wt; k.R = a.R; k.zeros = ctx->zeros;
   k.bias = a.bias; k.rowvec = a.rowvec; k.C = a.C;

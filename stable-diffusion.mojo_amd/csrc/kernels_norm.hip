@@ -176,6 +176,7 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   k.eps = eps; k.gamma = gamma; k.silu = silu; k.y = y; k.ldy = ldy;
   k.apply_pixels = 64;
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_GROUPNORM);
   hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)2 * C * sizeof(float), ctx->stream, k);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
 int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy) {
   if (C % 8 || C > 64 * 8 * LN_MAX_CH) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d unsupported", C);
   if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_LAYERNORM);
   hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps, y,
                      ldy);
   HIP_TRY(hipGetLastError());

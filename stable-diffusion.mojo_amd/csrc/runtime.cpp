@@ -80,6 +80,28 @@ extern "C" int tsd_ctx_timer_stop(tsd_ctx* c, float* ms) {
   return TSD_OK;
 }
 
+extern "C" int tsd_ctx_profile_begin(tsd_ctx* c) {
+  if (!c) TSD_FAIL(TSD_E_ARG, "ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->profile = true;
+  c->prof_n = 0;
+  return TSD_OK;
+}
+extern "C" int tsd_ctx_profile_end(tsd_ctx* c, float* ms_per_class, int* launches_per_class, int nclass) {
+  if (!c || !ms_per_class || !launches_per_class) TSD_FAIL(TSD_E_ARG, "profile_end: NULL argument");
+  c->profile = false;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nclass; i++) { ms_per_class[i] = 0.f; launches_per_class[i] = 0; }
+  for (size_t i = 0; i < c->prof_n; i++) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    const int k = c->prof_cls[i];
+    if (k >= 0 && k < nclass) { ms_per_class[k] += ms; launches_per_class[k]++; }
+  }
+  c->prof_n = 0;
+  return TSD_OK;
+}
+
 int ctx_reserve_arena(tsd_ctx* c, size_t bytes) {
   if (c->arena.cap >= bytes) return TSD_OK;
   HIP_TRY(hipSetDevice(c->device));

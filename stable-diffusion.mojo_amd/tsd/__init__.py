@@ -1,0 +1,23 @@
+"""tsd - Python host side of libtsd.so, mirroring the reference's Mojo modules for the hot path.
+
+  tsd.utils      <-> helpers/utils.mojo     Conv2D, GroupNorm, SiLU, Gelu, Linear, Upsample, LayerNorm, Softmax, ...
+  tsd.attention  <-> helpers/attention.mojo Self_Attention, Cross_Attention
+  tsd.diffusion  <-> diffusion.mojo         Time_Embedding, Unet_Residual_Block, Unet_Attention_Block, UNet, Diffusion
+  tsd.vae        <-> vae.mojo               Attention_Block, Res_Block, Decoder, Encoder
+  tsd.sampler    <-> sampler.mojo           DDPMSampler
+  tsd.pipeline   <-> pipeline.mojo          generate (hot loop only; CLIP/tokenizer out of scope)
+
+Every forward() is a call through the C ABI in include/tsd.h into hand-written HIP kernels for gfx950.
+There is no CPU fallback.
+"""
+from . import _lib, rng  # noqa: F401
+from ._lib import Context, TsdError, default_context, set_default_context, set_strict  # noqa: F401
+from .model import Model, Session, flop_count, param_specs  # noqa: F401
+from .utils import (Conv2D, Gelu, GroupNorm, LayerNorm, Linear, SiLU, Softmax, Upsample, concat,  # noqa: F401
+                    get_time_embedding, matmul, pad, rescale)
+from .attention import Cross_Attention, Self_Attention  # noqa: F401
+from .diffusion import (Diffusion, Time_Embedding, UNet, UNet_Output_Layer, Unet_Attention_Block,  # noqa: F401
+                        Unet_Residual_Block)
+from .vae import Attention_Block, Decoder, Encoder, Res_Block  # noqa: F401
+from .sampler import DDPMSampler  # noqa: F401
+from .pipeline import generate  # noqa: F401

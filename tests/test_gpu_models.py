@@ -1,0 +1,172 @@
+"""GPU parity of the module-level path (device-resident weights): Diffusion.forward, Decoder.forward,
+Encoder.forward, the denoise session, and size-independent properties (batch invariance, CFG-batch ==
+two passes, device RNG == host RNG, per-struct composition == fused module)."""
+import numpy as np
+import pytest
+
+from oracle import models, ops, rng, sampler, spec
+from util import TOL_MODEL, assert_close, rel_l2
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+
+@pytest.fixture(scope="module")
+def diffusion(gpu_ctx, tsd_mod):
+    return tsd_mod.Diffusion(seed=SEED)  # device-side counter-RNG init
+
+
+@pytest.fixture(scope="module")
+def decoder(gpu_ctx, tsd_mod):
+    return tsd_mod.Decoder(seed=SEED)
+
+
+@pytest.fixture(scope="module")
+def dec_params():
+    return spec.init_params("decoder", SEED, only_used=True)
+
+
+def _inputs(B, L, T=77, tag=500):
+    lat = rng.normal(SEED, tag, B * 4 * L * L).reshape(B, 4, L, L)
+    ctx = rng.normal(SEED, tag + 1, B * T * 768).reshape(B, T, 768)
+    return lat, ctx
+
+
+@pytest.mark.parametrize("L", [8, 16])
+def test_diffusion_forward_matches_oracle(L, diffusion, unet_params):
+    B = 2
+    lat, ctx = _inputs(B, L)
+    temb = np.stack([ops.time_embedding(980.0), ops.time_embedding(20.0)])
+    out = diffusion.forward(lat, ctx, temb)
+    ref = np.stack([models.diffusion(unet_params, lat[b], ctx[b], temb[b]) for b in range(B)])
+    assert_close(out, ref, TOL_MODEL, None, f"Diffusion.forward L={L}")
+
+
+def test_device_rng_equals_host_rng(gpu_ctx, tsd_mod, diffusion, unet_params):
+    """init_random on the device == uploading the numpy-generated weights: outputs must be bit-identical."""
+    full = spec.init_params("diffusion", SEED)  # includes the unused tensors
+    other = tsd_mod.Diffusion(params=full)
+    lat, ctx = _inputs(1, 8, tag=510)
+    temb = ops.time_embedding(500.0)[None]
+    a = diffusion.forward(lat, ctx, temb)
+    b = other.forward(lat, ctx, temb)
+    other.model.close()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_batch_invariance(diffusion):
+    """B samples in one call == B single-sample calls (nothing couples samples; GroupNorm is per sample)."""
+    lat, ctx = _inputs(3, 8, tag=520)
+    temb = np.stack([ops.time_embedding(t) for t in (900.0, 500.0, 0.0)])
+    batched = diffusion.forward(lat, ctx, temb)
+    for b in range(3):
+        single = diffusion.forward(lat[b], ctx[b], temb[b])
+        assert rel_l2(single, batched[b]) < 1e-3, b
+
+
+def test_context_tail_tokens(diffusion, unet_params):
+    """Context lengths that are not a multiple of 8 / 64 (77 in the reference; 5 here) are masked correctly."""
+    lat, ctx = _inputs(1, 8, T=5, tag=530)
+    temb = ops.time_embedding(300.0)[None]
+    out = diffusion.forward(lat, ctx, temb)
+    ref = models.diffusion(unet_params, lat[0], ctx[0], temb[0])[None]
+    assert_close(out, ref, TOL_MODEL, None, "Diffusion.forward T=5")
+
+
+def test_decoder_forward_matches_oracle(decoder, dec_params):
+    lat = rng.normal(SEED, 540, 2 * 4 * 8 * 8).reshape(2, 4, 8, 8) * 0.18215
+    out = decoder.forward(lat)
+    ref = np.stack([models.decoder(dec_params, lat[b]) for b in range(2)])
+    assert out.shape == (2, 3, 64, 64)
+    assert_close(out, ref, TOL_MODEL, None, "Decoder.forward L=8")
+
+
+def test_encoder_forward_matches_oracle(gpu_ctx, tsd_mod):
+    P = spec.init_params("encoder", SEED, only_used=True)
+    enc = tsd_mod.Encoder(seed=SEED)
+    img = rng.uniform(SEED, 550, 3 * 64 * 64, 1.0).reshape(1, 3, 64, 64)
+    noise = rng.normal(SEED, 551, 4 * 8 * 8).reshape(1, 4, 8, 8)
+    out = enc.forward(img, noise)
+    ref = models.encoder(P, img[0], noise[0])[None]
+    enc.model.close()
+    assert_close(out, ref, TOL_MODEL, None, "Encoder.forward S=64")
+
+
+def test_session_denoise_matches_oracle(gpu_ctx, tsd_mod, diffusion, unet_params):
+    """3 DDPM steps of the device-resident loop (UNet + fused DDPM update) vs the oracle loop."""
+    B, L, steps = 1, 8, 3
+    lat, ctx = _inputs(B, L, tag=560)
+    noise = rng.normal(SEED, 562, steps * B * 4 * L * L).reshape(steps, B, 4, L, L)
+    s = tsd_mod.Session(diffusion.model, None, B, L, 77, cfg=False)
+    s.set_schedule(1000, steps, 0)
+    assert [s.timestep(i) for i in range(s.num_steps)] == [666, 333, 0]
+    s.upload(lat, ctx, None, noise)
+    for i in range(steps):
+        s.step(i)
+    out = s.latents()
+    s.close()
+    ref = sampler.denoise(unet_params, lat[0], ctx[0], steps, noise[:, 0])[None]
+    assert_close(out, ref, TOL_MODEL, None, "session 3 steps")
+
+
+def test_cfg_batch_equals_two_passes(gpu_ctx, tsd_mod, diffusion):
+    """CFG: one UNet call on 2B (cond + uncond) then eps = s(e_c - e_u) + e_u == two separate passes (App.A D10)."""
+    B, L = 1, 8
+    lat, ctx = _inputs(B, L, tag=570)
+    _, uctx = _inputs(B, L, tag=580)
+    s = tsd_mod.Session(diffusion.model, None, B, L, 77, cfg=True)
+    s.set_schedule(1000, 2, 0)
+    s.upload(lat, ctx, uctx, None, cfg_scale=7.5)
+    s.step(0)
+    got = s.latents()
+    s.close()
+    t = 500
+    temb = ops.time_embedding(float(t))[None]
+    e_c = diffusion.forward(lat, ctx, temb)
+    e_u = diffusion.forward(lat, uctx, temb)
+    eps = sampler.cfg_combine(e_c, e_u, 7.5)
+    sm = sampler.DDPMSampler(1000)
+    sm.set_inference_timesteps(2)
+    ref = sm.step(t, lat, eps, np.zeros_like(lat))
+    assert rel_l2(got, ref) < 2e-3
+
+
+def test_generate_pipeline_runs(gpu_ctx, tsd_mod, diffusion, decoder):
+    """BASELINE config-1 style plumbing on the GPU: loop + decode + rescale gives finite images in [0,255]."""
+    _, ctx = _inputs(2, 8, tag=590)
+    img = tsd_mod.generate(diffusion, decoder, ctx, cfg=False, inference_steps=3, seed_val=11, L=8)
+    assert img.shape == (2, 3, 64, 64) and np.isfinite(img).all()
+    assert img.min() >= 0.0 and img.max() <= 255.0
+
+
+def test_per_struct_composition_equals_fused_module(gpu_ctx, tsd_mod, unet_params):
+    """`UNet` composed from the per-struct calls (diffusion.mojo:228-273 literally, incl. concats and Upsample)
+    == the fused device graph behind `Diffusion.forward` (dead-concat elimination, folded upsample)."""
+    P = unet_params
+    u = tsd_mod.UNet()
+    def setc(c, name): c.kernel, c.bias = P[name + ".kernel"], P[name + ".bias"]
+    def setl(l, name, bias=True):
+        l.weight = P[name + ".weight"]
+        if bias: l.bias = P[name + ".bias"]
+    for i, (kind, a) in enumerate(spec.UNET_LAYERS, start=1):
+        n, layer = f"unet.layer{i}", getattr(u, f"layer{i}")
+        if kind == "conv":
+            setc(layer, n)
+        elif kind == "res":
+            setc(layer.layer2, n + ".layer2"); setl(layer.layer3, n + ".layer3"); setc(layer.layer5, n + ".layer5")
+            if a[0] != a[1]: setc(layer.layer6, n + ".layer6")
+        elif kind == "attn":
+            setc(layer.layer2, n + ".layer2"); setl(layer.layer4.in_proj, n + ".layer4.in_proj", False)
+            setl(layer.layer4.out_proj, n + ".layer4.out_proj")
+            for p in ("q_proj", "k_proj", "v_proj"): setl(getattr(layer.layer6, p), n + ".layer6." + p, False)
+            setl(layer.layer6.out_proj, n + ".layer6.out_proj"); setl(layer.layer8, n + ".layer8")
+            setl(layer.layer9, n + ".layer9"); setc(layer.layer10, n + ".layer10")
+    te = tsd_mod.Time_Embedding(320)
+    setl(te.layer1, "time_embed.layer1"); setl(te.layer2, "time_embed.layer2")
+    fin = tsd_mod.UNet_Output_Layer(320, 4)
+    setc(fin.layer2, "final.layer2")
+    lat, ctx = _inputs(1, 8, tag=600)
+    t320 = tsd_mod.get_time_embedding(700.0)
+    out = fin.forward(u.forward(lat[0], ctx[0], te.forward(t320)))
+    ref = models.diffusion(P, lat[0], ctx[0], ops.time_embedding(700.0))
+    assert_close(out, ref, TOL_MODEL, None, "per-struct UNet composition")

@@ -1,0 +1,60 @@
+"""GPU parity: every op- and block-level C-ABI entry point against the CPU oracle on the same seeded inputs.
+
+Tolerances are stated in tests/util.py (fp16 storage / fp32 accumulate on the device vs fp32 oracle)."""
+import numpy as np
+import pytest
+
+from cases import CASES
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_case_matches_oracle(name, gpu_ctx, tsd_mod):
+    c = CASES[name]
+    inputs = c.build()
+    ref = np.asarray(c.oracle(inputs), dtype=np.float32)
+    y = np.asarray(c.device(tsd_mod, inputs), dtype=np.float32)
+    if c.tol == 0.0:
+        np.testing.assert_array_equal(y, ref)  # pure data movement: bit-exact
+    else:
+        assert_close(y, ref, c.tol, c.tol_max, what=name)
+
+
+def test_inputs_not_mutated(gpu_ctx, tsd_mod):
+    """The reference mutates inputs through aliasing (App.A D14/D16); the C ABI must not."""
+    c = CASES["unet_res_320_320"]
+    i = c.build()
+    x0, t0 = i["x"].copy(), i["time"].copy()
+    c.device(tsd_mod, i)
+    np.testing.assert_array_equal(i["x"], x0)
+    np.testing.assert_array_equal(i["time"], t0)
+
+
+def test_shape_errors_follow_reference_convention(gpu_ctx, tsd_mod, capsys):
+    """Shape errors: status TSD_E_SHAPE -> print + null matrix (helpers/utils.mojo:1955-1957) unless strict."""
+    tsd_mod.set_strict(False)
+    try:
+        y = tsd_mod.GroupNorm(32, 64).forward(np.zeros((32, 4, 4), np.float32))  # num_channels > C (:1847-1849)
+        assert y.shape == (0, 0, 0)
+        assert "null matrix" in capsys.readouterr().out
+        y = tsd_mod.Linear(16, 8).forward(np.zeros((1, 3, 17), np.float32))
+        assert y.shape == (0, 0, 0)
+    finally:
+        tsd_mod.set_strict(True)
+    with pytest.raises(tsd_mod.TsdError):
+        tsd_mod.GroupNorm(32, 64).forward(np.zeros((32, 4, 4), np.float32))
+
+
+def test_upsample_fusion_equals_materialised(gpu_ctx, tsd_mod):
+    """Upsample folded into the next conv's addressing == explicit Upsample then Conv2D (op level)."""
+    from oracle import ops
+    from util import randn, uni
+    x = randn(300, 64, 6, 6)
+    w = uni(301, 0.05, 64, 64, 3, 3)
+    c = tsd_mod.Conv2D(64, 64, 3, (1, 1))
+    c.kernel = w
+    y = c.forward(tsd_mod.Upsample(2).forward(x))
+    ref = ops.conv2d(ops.upsample_nearest2x(x), w, None, padding=(1, 1))
+    assert_close(y, ref, 3e-3, 1e-2, "upsample+conv")

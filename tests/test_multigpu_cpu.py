@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: two `gloo` processes exercise bench.py's sharding and the weight-broadcast protocol
+(rank 0 owns the blob, every other rank receives identical bytes, batch shards are disjoint and cover the
+global batch).  No GPU needed; the RCCL transport itself is exercised by the driver's multi-GPU run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "stable-diffusion.mojo_amd"))
+    import bench
+    import tsd.rng as prng
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # weight blob: rank 0 generates, everyone else starts from garbage and must end up bit-identical
+    n = 1 << 16
+    blob = torch.from_numpy(prng.uniform(1234, 4096 + 7, n, 0.05).copy()) if rank == 0 else torch.full((n,), float("nan"))
+    dist.broadcast(blob, 0)
+    ref = prng.uniform(1234, 4096 + 7, n, 0.05)
+    ok_blob = bool(np.array_equal(blob.numpy(), ref))
+    # batch shards of a global batch of world*8 prompts
+    lo, hi = bench.shard_range(world * 8, rank, world)
+    ids = torch.zeros(world * 8, dtype=torch.int64)
+    ids[lo:hi] = 1
+    dist.all_reduce(ids)
+    # timing reduction = MAX over ranks (bench contract)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    out[rank] = (ok_blob, hi - lo, bool((ids == 1).all()), float(t.item()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_broadcast():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        ok_blob, nshard, cover, tmax = out[r]
+        assert ok_blob and nshard == 8 and cover and tmax == 2.0
+
+
+@pytest.mark.parametrize("total,world", [(64, 8), (16, 2), (8, 1), (10, 3)])
+def test_shard_range_partitions(total, world):
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = []
+    for r in range(world):
+        lo, hi = bench.shard_range(total, r, world)
+        seen += list(range(lo, hi))
+    assert seen == list(range(total))
