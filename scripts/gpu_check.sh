@@ -15,3 +15,12 @@ timeout 900 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2 ${BENCH_ARGS:-
 cat gpurun_out/summary.txt
 grep -hE "passed|failed|error" gpurun_out/test_*.log | tail -5
 tail -n 3 gpurun_out/bench.log
+if [ "${PROFILE:-0}" = "1" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  R="${GRAFT_REPO_ROOT:-/root/repo}"
+  rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decode > $R/gpurun_out/prof_bench.log 2>&1
+  find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $R/gpurun_out/kernel_stats.csv \;
+  find /tmp/prof -name "*kernel_trace*.csv" -exec sh -c 'head -c 3000000 "$1" > '$R'/gpurun_out/kernel_trace_head.csv' _ {} \;
+  ls -R /tmp/prof | head -20 > $R/gpurun_out/prof_ls.txt
+  head -n 40 $R/gpurun_out/kernel_stats.csv
+fi

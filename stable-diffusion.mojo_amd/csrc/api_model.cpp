@@ -145,7 +145,7 @@ extern "C" int tsd_session_create(tsd_model* diffusion, tsd_model* decoder, int 
   if (decoder && (decoder->kind != TSD_MODEL_DECODER || decoder->ctx != diffusion->ctx))
     TSD_FAIL(TSD_E_ARG, "session: decoder must be a Decoder on the same context");
   const int Bu = cfg ? 2 * B : B;
-  if (B <= 0 || Bu > 16 || L <= 0 || L % 4 || T <= 0) TSD_FAIL(TSD_E_SHAPE, "session: B=%d (UNet batch %d <= 16) L=%d T=%d", B, Bu, L, T);
+  if (B <= 0 || Bu > 16 || L <= 0 || L % 8 || T <= 0) TSD_FAIL(TSD_E_SHAPE, "session: B=%d (UNet batch %d <= 16) L=%d T=%d", B, Bu, L, T);
   tsd_ctx* ctx = diffusion->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
   tsd_session* s = new tsd_session();

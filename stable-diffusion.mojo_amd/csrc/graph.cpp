@@ -91,7 +91,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   const int64_t M = (int64_t)B * S;
   if (C % 64 || x.C != C) TSD_FAIL(TSD_E_SHAPE, "attention block: C=%d (input %d) unsupported", C, x.C);
   if (!attn_fused_supported(d)) TSD_FAIL(TSD_E_SHAPE, "attention block: head dim %d unsupported (40/80/160)", d);
-  if (S % 8) TSD_FAIL(TSD_E_SHAPE, "attention block: H*W=%d must be a multiple of 8", S);
+  if (S % 4) TSD_FAIL(TSD_E_SHAPE, "attention block: H*W=%d must be a multiple of 4", S);
   const size_t mark = ctx->arena.mark();
   const float scale = 1.f / sqrtf((float)d);  // helpers/attention.mojo:57-58
   half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
@@ -103,6 +103,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
   const int Sp = round_up(S, 8);
   half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * Sp); CHECK_ALLOC(vt);
+  if (Sp != S) TSD_TRY(zero_async(ctx, vt, (size_t)B * C * Sp * sizeof(half_t)));  // pad keys must be finite (P = 0 there)
   half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
   // ---- self attention (:122-126) ----
   TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C));
@@ -248,7 +249,7 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
                    int L, float* eps_out_chw) {
   tsd_ctx* ctx = m->ctx;
   const UNetW& u = m->unet;
-  if (L % 4) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 4", L);
+  if (L % 8) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 8", L);
   // ---- time path (diffusion.mojo:17-21 and :61-62 for all nine residual blocks) ----
   float* t1 = arena_alloc<float>(ctx, (int64_t)B * 1280); CHECK_ALLOC(t1);
   float* time = arena_alloc<float>(ctx, (int64_t)B * 1280); CHECK_ALLOC(time);

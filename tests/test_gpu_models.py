@@ -121,14 +121,16 @@ def test_cfg_batch_equals_two_passes(gpu_ctx, tsd_mod, diffusion):
     got = s.latents()
     s.close()
     t = 500
-    temb = ops.time_embedding(float(t))[None]
+    # the device-computed embedding, so both routes see bit-identical inputs: the CFG combine amplifies the
+    # (deterministic) fp16 rounding pattern of the two passes 7.5x, so even a 1e-7 input change decorrelates it
+    temb = tsd_mod.get_time_embedding(float(t)).reshape(1, 320)
     e_c = diffusion.forward(lat, ctx, temb)
     e_u = diffusion.forward(lat, uctx, temb)
     eps = sampler.cfg_combine(e_c, e_u, 7.5)
     sm = sampler.DDPMSampler(1000)
     sm.set_inference_timesteps(2)
     ref = sm.step(t, lat, eps, np.zeros_like(lat))
-    assert rel_l2(got, ref) < 2e-3
+    assert rel_l2(got, ref) < 1e-5
 
 
 def test_generate_pipeline_runs(gpu_ctx, tsd_mod, diffusion, decoder):
