@@ -67,6 +67,9 @@ int tsd_ctx_timer_stop(tsd_ctx* ctx, float* elapsed_ms);
  * 3 GroupNorm, 4 LayerNorm, 5 tiny-M linear, 6 elementwise/layout, 7 row softmax.  nclass <= 8. */
 int tsd_ctx_profile_begin(tsd_ctx* ctx);
 int tsd_ctx_profile_end(tsd_ctx* ctx, float* ms_per_class, int* launches_per_class, int nclass);
+/* Per-launch records of the current profiling pass (call BEFORE profile_end, which resets):
+ * rec[i] = {class, M, N, K, batch} (GEMM-class launches; Sq,Sk,d,B*H for attention), ms[i]; returns the count. */
+int tsd_ctx_profile_records(tsd_ctx* ctx, int* rec, float* ms, int cap);
 
 /* ---- op level: one export per reference op struct (host fp32 in/out) ------------------ */
 
@@ -220,6 +223,12 @@ int tsd_dist_unique_id(void* id128);
 int tsd_dist_init(tsd_ctx* ctx, int rank, int nranks, const void* id128);
 int tsd_dist_broadcast_weights(tsd_model* m, int root); /* ncclBroadcast of the packed blob */
 int tsd_dist_finalize(tsd_ctx* ctx);
+
+/* ---- debug / tuning -------------------------------------------------------------------- */
+/* Time one GEMM (conv = 0: M = B*H*W, K = Cin) or conv3x3 problem on synthetic device data with tile
+ * configuration `cfg` (< 0: dispatcher's choice); average ms per launch over `iters` launches. */
+int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
+                         int iters, float* ms);
 
 /* ---- census -------------------------------------------------------------------------- */
 /* Algorithmic GFLOP (2*MAC of conv + linear + attention core) of one forward per sample

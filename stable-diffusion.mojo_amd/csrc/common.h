@@ -63,6 +63,7 @@ struct tsd_ctx {
   bool profile = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
   std::vector<int> prof_cls;
+  std::vector<int> prof_shape;  // 4 ints per record (M, N, K, batch) - 0 when not a GEMM
   size_t prof_n = 0;
 };
 
@@ -73,14 +74,18 @@ enum KernelClass : int {
 // RAII: records a start/stop event pair around the launches in its scope when profiling is on
 struct ProfScope {
   tsd_ctx* c; bool on;
-  ProfScope(tsd_ctx* ctx, int cls) : c(ctx), on(ctx->profile && ctx->launch()) {
+  ProfScope(tsd_ctx* ctx, int cls, int M = 0, int N = 0, int K = 0, int batch = 0)
+      : c(ctx), on(ctx->profile && ctx->launch()) {
     if (!on) return;
     if (c->prof_n * 2 + 2 > c->prof_ev.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
       c->prof_ev.push_back(a); c->prof_ev.push_back(b);
     }
-    if (c->prof_cls.size() <= c->prof_n) c->prof_cls.push_back(cls); else c->prof_cls[c->prof_n] = cls;
+    if (c->prof_cls.size() <= c->prof_n) { c->prof_cls.push_back(cls); c->prof_shape.resize(4 * c->prof_cls.size()); }
+    else c->prof_cls[c->prof_n] = cls;
+    int* sh = &c->prof_shape[4 * c->prof_n];
+    sh[0] = M; sh[1] = N; sh[2] = K; sh[3] = batch;
     (void)hipEventRecord(c->prof_ev[c->prof_n * 2], c->stream);
   }
   ~ProfScope() {

@@ -40,7 +40,9 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const AttnK p) {
+// min 2 waves/SIMD: caps the budget at 256 unified registers so the MFMA results stay in VGPRs (no v_accvgpr moves
+// around the softmax / rescale VALU work).
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   constexpr int DCH = D / 8;               // 16-B chunks per K row
   constexpr int KSTEPS = (DCH + 1) / 2;    // QK^T k-steps (16 wide)
   constexpr int KPITCH = (2 * KSTEPS) | 1; // LDS pitch of a K row in chunks (odd -> conflict-free)
@@ -247,7 +249,7 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4) TSD_FAIL(TSD_E_SHAPE, "flash attention: misaligned pitches");
   if (a.Sq <= 0 || a.Sk <= 0) TSD_FAIL(TSD_E_SHAPE, "flash attention: empty sequence");
   if (!ctx->launch()) return TSD_OK;
-  ProfScope prof(ctx, KC_ATTN);
+  ProfScope prof(ctx, KC_ATTN, a.Sq, a.Sk, a.d, a.B * a.H);
   AttnK k;
   k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros;
   k.sQ = a.sQ; k.sK = a.sK; k.sVt = a.sVt; k.sO = a.sO;

@@ -50,8 +50,14 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.f + t);
 }
 
-template <int WGM, int WGN, int FM, int FN, bool CONV>
-__global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_kernel(const GemmK p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NS = LDS ring depth.  NS == 2: two blocks per CU hide the DMA latency by TLP (big M).  NS >= 3: one block per
+// CU with NS-1 K-tiles of DMA in flight behind counted s_waitcnt vmcnt (few-tile problems: M = 2048 level of the
+// UNet, where only 256 tiles exist and every iteration would otherwise expose a full HBM/L2 round trip).
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS>
+__global__ __launch_bounds__(WGM* WGN * 64, (NS <= 2 ? 2 : 1)) void gemm_kernel(const GemmK p) {
   constexpr int NW = WGM * WGN;
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int BMw = FM * 16, BNw = FN * 16;
@@ -208,14 +214,24 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_kernel(const GemmK p) {
   };
 
   const int nk = p.K >> 6;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  constexpr int LPS = A_PW + W_PW;  // DMA instructions per stage per wave (when evenly divisible)
+  static_assert(NS == 2 || (A_INSTR % NW == 0 && W_INSTR % NW == 0), "counted vmcnt needs equal loads per wave");
+#pragma unroll
+  for (int s = 0; s < NS - 1; s++)
+    if (s < nk) stage(s, s);
+  int cur = 0, nxt = NS - 1;  // ring slots of tile kt and tile kt+NS-1
   for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
+    const int ahead = min(NS - 2, nk - 1 - kt);
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * LPS>();
+    else if (NS >= 3 && ahead == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+    compute(cur);
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
 
   // ---- epilogue ---------------------------------------------------------------------------
@@ -301,11 +317,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_kernel(const GemmK p) {
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int WGM, int WGN, int FM, int FN, bool CONV>
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2>
 static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
-  constexpr int LDS = 2 * (BM + BN) * 128;
-  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV>;
+  constexpr int LDS = NS * (BM + BN) * 128;
+  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -320,17 +336,98 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   return TSD_OK;
 }
 
+// tile configurations: {wave grid M x N, fragments per wave M x N, LDS ring depth}
+//  id  tile      stages  LDS      use
+//   0  128x160   2       72 KiB   big-M UNet widths (N % 160 == 0), 2 blocks/CU
+//   1   64x160   2       56 KiB   mid-M
+//   2  128x128   2       64 KiB   VAE widths
+//   3   64x128   2       48 KiB
+//   4  128x16    2       36 KiB   N <= 16 (final 320->4, decoder 128->3)
+//   5  128x160   3      108 KiB   deep ring, 1 block/CU
+//   6   64x160   4      112 KiB   few-tile problems (M = 2048 level)
+//   7   64x160   3       84 KiB
+//   8  128x128   3       96 KiB
+//   9   64x128   4       96 KiB
+//  10   64x128   3       72 KiB
+constexpr int N_GEMM_CFG = 11;
+static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
+
 template <bool CONV>
-static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
-  const int M = k.M, N = k.N;
-  if (N <= 16) return launch_cfg<4, 1, 2, 1, CONV>(ctx, k, batch);
+static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
+  switch (id) {
+    case 0: return launch_cfg<2, 2, 4, 5, CONV, 2>(ctx, k, batch);
+    case 1: return launch_cfg<2, 2, 2, 5, CONV, 2>(ctx, k, batch);
+    case 2: return launch_cfg<2, 2, 4, 4, CONV, 2>(ctx, k, batch);
+    case 3: return launch_cfg<2, 2, 2, 4, CONV, 2>(ctx, k, batch);
+    case 4: return launch_cfg<4, 1, 2, 1, CONV, 2>(ctx, k, batch);
+    case 5: return launch_cfg<2, 2, 4, 5, CONV, 3>(ctx, k, batch);
+    case 6: return launch_cfg<2, 2, 2, 5, CONV, 4>(ctx, k, batch);
+    case 7: return launch_cfg<2, 2, 2, 5, CONV, 3>(ctx, k, batch);
+    case 8: return launch_cfg<2, 2, 4, 4, CONV, 3>(ctx, k, batch);
+    case 9: return launch_cfg<2, 2, 2, 4, CONV, 4>(ctx, k, batch);
+    case 10: return launch_cfg<2, 2, 2, 4, CONV, 3>(ctx, k, batch);
+    default: TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
+  }
+}
+
+static int choose_cfg(int M, int N, int K, int batch) {
+  if (N <= 16) return 4;
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
-  // prefer 128-row tiles when they still give every CU at least one tile
-  const long long tiles128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
-  const bool big = tiles128 >= 256;
-  if (n160) return big ? launch_cfg<2, 2, 4, 5, CONV>(ctx, k, batch) : launch_cfg<2, 2, 2, 5, CONV>(ctx, k, batch);
-  return big ? launch_cfg<2, 2, 4, 4, CONV>(ctx, k, batch) : launch_cfg<2, 2, 2, 4, CONV>(ctx, k, batch);
+  // measured on MI355X (scripts/bench_gemm.py): two 128-row blocks per CU win once there are >= 2 tiles per CU;
+  // below that 64-row tiles; with <= 1 tile per CU only a deep DMA ring keeps the MFMA pipe fed.
+  const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
+  const long long t64 = (long long)ceil_div(M, 64) * ceil_div(N, BN) * batch;
+  if (t128 >= 512) return n160 ? 0 : 2;
+  if (t64 >= 512) return n160 ? 1 : 3;
+  return n160 ? 7 : 10;
+}
+
+template <bool CONV>
+static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
+  const int id = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(k.M, k.N, k.K, batch);
+  return launch_by_id<CONV>(ctx, k, batch, id);
+}
+
+// Debug/bench entry: time `iters` launches of one GEMM / conv3x3 problem on synthetic device data with a forced
+// tile configuration (cfg < 0: the dispatcher's choice).  conv: M = B*Ho*Wo from (B,H,W,stride,ups), K = 9*Cin.
+extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups,
+                                    int cfg, int iters, float* ms) {
+  if (!ctx || !ms || iters <= 0) TSD_FAIL(TSD_E_ARG, "gemm_bench: bad argument");
+  if (cfg >= N_GEMM_CFG) TSD_FAIL(TSD_E_ARG, "gemm_bench: cfg %d out of range", cfg);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int Hi = ups ? 2 * H : H, Wi = ups ? 2 * W : W;
+  const int Ho = conv ? (Hi + 2 - 3) / stride + 1 : H, Wo = conv ? (Wi + 2 - 3) / stride + 1 : W;
+  const int64_t M = (int64_t)B * Ho * Wo, K = conv ? 9 * (int64_t)Cin : Cin;
+  const int64_t na = (int64_t)B * H * W * Cin, nw = (int64_t)N * K, nc = M * N;
+  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + nc) * 2 + (size_t)std::max(na, nw) * 4 + 4096));
+  ctx->arena.top = 0;
+  half_t* A = arena_alloc<half_t>(ctx, na);
+  half_t* Wt = arena_alloc<half_t>(ctx, nw);
+  half_t* C = arena_alloc<half_t>(ctx, nc);
+  float* tmp = arena_alloc<float>(ctx, std::max(na, nw));
+  if (!A || !Wt || !C || !tmp) TSD_FAIL(TSD_E_ALLOC, "gemm_bench: arena");
+  TSD_TRY(launch_fill_uniform(ctx, tmp, na, 1, 1, 1.f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)std::min<int64_t>(na, 1 << 30), A, (int)std::min<int64_t>(na, 1 << 30), 1));
+  TSD_TRY(launch_fill_uniform(ctx, tmp, nw, 1, 2, 0.05f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nw, Wt, (int)nw, 1));
+  GemmArgs g;
+  g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.C = C; g.ldc = N;
+  if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
+  g_force_cfg = cfg;
+  int r = launch_gemm(ctx, g);
+  if (r == TSD_OK) r = launch_gemm(ctx, g);
+  if (r != TSD_OK) { g_force_cfg = -1; return r; }
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < iters && r == TSD_OK; i++) r = launch_gemm(ctx, g);
+  g_force_cfg = -1;
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+  *ms = t / iters;
+  ctx->arena.top = 0;
+  return r;
 }
 
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
@@ -345,7 +442,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     if (a.K0 % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: concat split K0=%d must be a multiple of 64", a.K0);
   }
   if (!ctx->launch()) return TSD_OK;
-  ProfScope prof(ctx, a.conv ? KC_CONV : KC_GEMM);
+  ProfScope prof(ctx, a.conv ? KC_CONV : KC_GEMM, a.M, a.N, a.K, a.batch);
   GemmK k;
   k.A0 = a.A0; k.A1 = a.A1; k.Wt = a.Wt; k.R = a.R; k.zeros = ctx->zeros;
   k.bias = a.bias; k.rowvec = a.rowvec; k.C = a.C;

@@ -5,9 +5,9 @@
 // Formula kept literal (App.A D12): y = (x - mu) / (sigma + eps) * gamma, population sigma,
 // eps added to sigma, scalar gamma, no beta.
 //
-// GroupNorm is two launches: per-slab partial (sum, sumsq) over full NHWC pixel rows (coalesced
-// 16-B loads, fp32 accumulation, deterministic - no atomics), then an apply pass that finishes
-// the statistics in double and streams the tensor once.  The source may be the channel-concat
+// GroupNorm is three launches: per-slab partial (sum, sumsq) over full NHWC pixel rows (coalesced
+// 16-B loads, 4 in flight per thread, fp32 accumulation, deterministic - no atomics), a tiny finalize
+// (statistics finished in double), then an apply pass that streams the tensor once.  The source may be the channel-concat
 // of two tensors (UNet skip connections, diffusion.mojo:253-270) so the concat is never
 // materialised for the normalised branch.
 #include "common.h"
@@ -15,12 +15,14 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int GN_MAX_CPT = 2;  // chunks (of 8 channels) per thread: C <= 4096
+constexpr int GN_UNROLL = 4;   // independent 16-B loads in flight per thread
 
 struct GnK {
   const half_t* x0; const half_t* x1;
   int ld0, ld1, C0, C, HW, G, cpg;
   int nslab, slab_pixels;
-  float* partial;  // [B][nslab][G][2]
+  float* partial;  // [B][nslab][G][2]  (sum, sumsq) per slab
+  float* stats;    // [B][G][2]         (mean, gamma/(sigma+eps))
   float eps, gamma;
   int silu;
   half_t* y; int ldy;
@@ -33,19 +35,23 @@ __device__ __forceinline__ h8 gn_load(const GnK& p, int64_t pixg, int ch) {
   return *(const h8*)(p.x1 + pixg * p.ld1 + (c - p.C0));
 }
 
+// thread -> (pixel lane pl, chunk column ch0): a thread always handles the same 8 (or 16) channels and
+// strides over pixels, so per-channel sums stay in registers.
+struct GnMap { int nch, PL, pl, ch0; bool active; };
+__device__ __forceinline__ GnMap gn_map(int C, int tid) {
+  GnMap m;
+  m.nch = C >> 3;
+  if (m.nch <= 256) { m.PL = 256 / m.nch; m.pl = tid / m.nch; m.ch0 = tid - m.pl * m.nch; m.active = tid < m.PL * m.nch; }
+  else { m.PL = 1; m.pl = 0; m.ch0 = tid; m.active = true; }
+  return m;
+}
+
 __global__ __launch_bounds__(256) void k_gn_partial(const GnK p) {
   extern __shared__ __attribute__((aligned(16))) char smem_gn[];
-  float* s1 = (float*)smem_gn;  // [C]
-  float* s2 = s1 + p.C;
+  float* red = (float*)smem_gn;  // [PL][2][C]
   const int tid = threadIdx.x;
-  const int nch = p.C >> 3;
+  const GnMap m = gn_map(p.C, tid);
   const int b = blockIdx.y, slab = blockIdx.x;
-  for (int i = tid; i < 2 * p.C; i += 256) s1[i] = 0.f;
-  __syncthreads();
-  const int PL = nch <= 256 ? 256 / nch : 1;     // pixel lanes
-  const int pl = nch <= 256 ? tid / nch : 0;
-  const int ch0 = nch <= 256 ? tid % nch : tid;
-  const bool active = nch <= 256 ? (tid < PL * nch) : true;
   float a1[GN_MAX_CPT][8], a2[GN_MAX_CPT][8];
 #pragma unroll
   for (int q = 0; q < GN_MAX_CPT; q++)
@@ -53,107 +59,128 @@ __global__ __launch_bounds__(256) void k_gn_partial(const GnK p) {
     for (int j = 0; j < 8; j++) a1[q][j] = a2[q][j] = 0.f;
   const int p_begin = slab * p.slab_pixels;
   const int p_end = min(p.HW, p_begin + p.slab_pixels);
-  if (active) {
-    for (int pix = p_begin + pl; pix < p_end; pix += PL) {
-      const int64_t pixg = (int64_t)b * p.HW + pix;
+  if (m.active) {
+    for (int pix0 = p_begin + m.pl; pix0 < p_end; pix0 += m.PL * GN_UNROLL) {
 #pragma unroll
       for (int q = 0; q < GN_MAX_CPT; q++) {
-        const int ch = ch0 + q * 256;
-        if (ch < nch) {
-          const h8 v = gn_load(p, pixg, ch);
+        const int ch = m.ch0 + q * 256;
+        if (ch < m.nch) {
+          h8 v[GN_UNROLL];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float f = (float)v[j];
-            a1[q][j] += f;
-            a2[q][j] += f * f;
+          for (int u = 0; u < GN_UNROLL; u++) {
+            const int pix = pix0 + u * m.PL;
+            v[u] = pix < p_end ? gn_load(p, (int64_t)b * p.HW + pix, ch) : h8{0, 0, 0, 0, 0, 0, 0, 0};
           }
+#pragma unroll
+          for (int u = 0; u < GN_UNROLL; u++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float f = (float)v[u][j];
+              a1[q][j] += f;
+              a2[q][j] += f * f;
+            }
         }
       }
     }
-    // combine pixel lanes: serialise over pl so the sum order is fixed (deterministic)
-  }
-  for (int turn = 0; turn < PL; turn++) {
-    if (active && pl == turn) {
 #pragma unroll
-      for (int q = 0; q < GN_MAX_CPT; q++) {
-        const int ch = ch0 + q * 256;
-        if (ch < nch) {
+    for (int q = 0; q < GN_MAX_CPT; q++) {
+      const int ch = m.ch0 + q * 256;
+      if (ch < m.nch) {
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            s1[ch * 8 + j] += a1[q][j];
-            s2[ch * 8 + j] += a2[q][j];
-          }
+        for (int j = 0; j < 8; j++) {
+          red[(m.pl * 2 + 0) * p.C + ch * 8 + j] = a1[q][j];
+          red[(m.pl * 2 + 1) * p.C + ch * 8 + j] = a2[q][j];
         }
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
+  // fixed-order (deterministic) reduction: pixel lanes, then the channels of each group
   for (int g = tid; g < p.G; g += 256) {
     float t1 = 0.f, t2 = 0.f;
-    for (int c = g * p.cpg; c < (g + 1) * p.cpg; c++) {
-      t1 += s1[c];
-      t2 += s2[c];
-    }
+    for (int c = g * p.cpg; c < (g + 1) * p.cpg; c++)
+      for (int l = 0; l < m.PL; l++) {
+        t1 += red[(l * 2 + 0) * p.C + c];
+        t2 += red[(l * 2 + 1) * p.C + c];
+      }
     float* o = p.partial + (((int64_t)b * p.nslab + slab) * p.G + g) * 2;
     o[0] = t1;
     o[1] = t2;
   }
 }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_gn[];
-  float* mean = (float*)smem_gn;  // [G]
-  float* rinv = mean + p.G;
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  for (int g = tid; g < p.G; g += 256) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int s = 0; s < p.nslab; s++) {
-      const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
-      t1 += (double)o[0];
-      t2 += (double)o[1];
-    }
+// one wave per (sample, group): lanes stride over the slabs, fixed-order butterfly in double (deterministic)
+__global__ __launch_bounds__(256) void k_gn_finalize(const GnK p, int total) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);  // b * G + g
+  if (idx >= total) return;
+  const int b = idx / p.G, g = idx - b * p.G;
+  double t1 = 0.0, t2 = 0.0;
+  for (int s = lane; s < p.nslab; s += 64) {
+    const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
+    t1 += (double)o[0];
+    t2 += (double)o[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    t1 += __shfl_xor(t1, o);
+    t2 += __shfl_xor(t2, o);
+  }
+  if (lane == 0) {
     const double n = (double)p.cpg * (double)p.HW;
     const double mu = t1 / n;
     double var = t2 / n - mu * mu;
     if (var < 0.0) var = 0.0;
-    mean[g] = (float)mu;
-    rinv[g] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));
+    float* st = p.stats + (int64_t)idx * 2;
+    st[0] = (float)mu;
+    st[1] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));  // eps added to sigma (helpers/utils.mojo:1871-1873)
   }
-  __syncthreads();
-  const int nch = p.C >> 3;
-  const int PL = nch <= 256 ? 256 / nch : 1;
-  const int pl = nch <= 256 ? tid / nch : 0;
-  const int ch0 = nch <= 256 ? tid % nch : tid;
-  if (nch <= 256 && tid >= PL * nch) return;
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const GnMap m = gn_map(p.C, tid);
+  if (!m.active) return;
   float mu[GN_MAX_CPT][8], ri[GN_MAX_CPT][8];
 #pragma unroll
   for (int q = 0; q < GN_MAX_CPT; q++) {
-    const int ch = ch0 + q * 256;
+    const int ch = m.ch0 + q * 256;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int g = ch < nch ? (ch * 8 + j) / p.cpg : 0;
-      mu[q][j] = mean[g];
-      ri[q][j] = rinv[g];
+      const int g = ch < m.nch ? (ch * 8 + j) / p.cpg : 0;
+      const float* st = p.stats + ((int64_t)b * p.G + g) * 2;
+      mu[q][j] = st[0];
+      ri[q][j] = st[1];
     }
   }
   const int p_begin = blockIdx.x * p.apply_pixels;
   const int p_end = min(p.HW, p_begin + p.apply_pixels);
-  for (int pix = p_begin + pl; pix < p_end; pix += PL) {
-    const int64_t pixg = (int64_t)b * p.HW + pix;
+  for (int pix0 = p_begin + m.pl; pix0 < p_end; pix0 += m.PL * GN_UNROLL) {
 #pragma unroll
     for (int q = 0; q < GN_MAX_CPT; q++) {
-      const int ch = ch0 + q * 256;
-      if (ch < nch) {
-        const h8 v = gn_load(p, pixg, ch);
-        h8 o;
+      const int ch = m.ch0 + q * 256;
+      if (ch < m.nch) {
+        h8 v[GN_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          float f = ((float)v[j] - mu[q][j]) * ri[q][j];
-          if (p.silu) f = f / (1.f + __expf(-f));
-          o[j] = (half_t)f;
+        for (int u = 0; u < GN_UNROLL; u++) {
+          const int pix = pix0 + u * m.PL;
+          if (pix < p_end) v[u] = gn_load(p, (int64_t)b * p.HW + pix, ch);
         }
-        *(h8*)(p.y + pixg * p.ldy + ch * 8) = o;
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; u++) {
+          const int pix = pix0 + u * m.PL;
+          if (pix < p_end) {
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              float f = ((float)v[u][j] - mu[q][j]) * ri[q][j];
+              if (p.silu) f = f / (1.f + __expf(-f));
+              o[j] = (half_t)f;
+            }
+            *(h8*)(p.y + ((int64_t)b * p.HW + pix) * p.ldy + ch * 8) = o;
+          }
+        }
       }
     }
   }
@@ -168,19 +195,22 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   GnK k;
   k.x0 = src.x0; k.x1 = src.x1; k.ld0 = src.ld0; k.ld1 = src.ld1; k.C0 = C0; k.C = C; k.HW = HW; k.G = groups;
   k.cpg = C / groups;
-  k.nslab = std::max(1, std::min(64, HW / 64));
-  k.slab_pixels = ceil_div(HW, k.nslab);
+  const int nch = C / 8, PL = nch <= 256 ? 256 / nch : 1;
+  // stats pass: 2*GN_UNROLL pixels per thread, at most 512 slabs per sample ; apply pass: GN_UNROLL pixels per thread
+  k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 512));
   k.nslab = ceil_div(HW, k.slab_pixels);
+  k.apply_pixels = GN_UNROLL * PL;
   k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
-  if (!k.partial) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
+  k.stats = arena_alloc<float>(ctx, (int64_t)B * groups * 2);
+  if (!k.partial || !k.stats) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
   k.eps = eps; k.gamma = gamma; k.silu = silu; k.y = y; k.ldy = ldy;
-  k.apply_pixels = 64;
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_GROUPNORM);
-  hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)2 * C * sizeof(float), ctx->stream, k);
+  hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
-                     ctx->stream, k);
+  hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(B * groups, 4)), dim3(256), 0, ctx->stream, k, B * groups);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), 0, ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

@@ -101,6 +101,19 @@ extern "C" int tsd_ctx_profile_end(tsd_ctx* c, float* ms_per_class, int* launche
   c->prof_n = 0;
   return TSD_OK;
 }
+// per-launch records of the last profiling pass: rec[i] = {class, M, N, K, batch}, ms[i]; returns the count
+extern "C" int tsd_ctx_profile_records(tsd_ctx* c, int* rec, float* ms, int cap) {
+  if (!c || !rec || !ms) TSD_FAIL(TSD_E_ARG, "profile_records: NULL argument");
+  c->profile = false;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int n = 0;
+  for (size_t i = 0; i < c->prof_n && n < cap; i++, n++) {
+    HIP_TRY(hipEventElapsedTime(&ms[n], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    rec[5 * n] = c->prof_cls[i];
+    for (int j = 0; j < 4; j++) rec[5 * n + 1 + j] = c->prof_shape[4 * i + j];
+  }
+  return n;
+}
 
 int ctx_reserve_arena(tsd_ctx* c, size_t bytes) {
   if (c->arena.cap >= bytes) return TSD_OK;

@@ -53,7 +53,7 @@ def _declare(l):
         "tsd_version": ([], i), "tsd_last_error": ([], C.c_char_p), "tsd_device_count": ([], i),
         "tsd_ctx_create": ([i, pp], i), "tsd_ctx_destroy": ([vp], i), "tsd_ctx_synchronize": ([vp], i),
         "tsd_ctx_timer_start": ([vp], i), "tsd_ctx_timer_stop": ([vp, fp], i),
-        "tsd_ctx_profile_begin": ([vp], i), "tsd_ctx_profile_end": ([vp, fp, C.POINTER(i), i], i),
+        "tsd_ctx_profile_begin": ([vp], i), "tsd_ctx_profile_records": ([vp, C.POINTER(i), fp, i], i), "tsd_ctx_profile_end": ([vp, fp, C.POINTER(i), i], i),
         "tsd_conv2d_f32": ([vp, fp, i, i, i, fp, fp, i, i, i, i, i, i, i, fp], i),
         "tsd_pad_f32": ([vp, fp, i, i, i, i, i, i, i, fp], i),
         "tsd_groupnorm_f32": ([vp, fp, i, i, i, i, i, f, f, fp], i),
@@ -89,6 +89,7 @@ def _declare(l):
         "tsd_dist_unique_id": ([vp], i), "tsd_dist_init": ([vp, i, i, vp], i),
         "tsd_dist_broadcast_weights": ([vp, i], i), "tsd_dist_finalize": ([vp], i),
         "tsd_flop_count": ([i, i, i], C.c_double),
+        "tsd_debug_gemm_bench": ([vp, i, i, i, i, i, i, i, i, i, i, fp], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(l, name)
@@ -169,6 +170,16 @@ class Context:
         n = (C.c_int * 8)()
         check(lib().tsd_ctx_profile_end(self.h, ms, n, 8))
         return {k: (ms[i], n[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
+
+    def profile_records(self, cap=8192):
+        """[(class, M, N, K, batch, ms)] per launch of the current profiling pass."""
+        rec = (C.c_int * (5 * cap))()
+        ms = (C.c_float * cap)()
+        n = lib().tsd_ctx_profile_records(self.h, rec, ms, cap)
+        if n < 0:
+            check(n)
+        return [(self.KERNEL_CLASSES[rec[5 * i]], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], ms[i])
+                for i in range(n)]
 
     def close(self):
         if self.h:
