@@ -230,6 +230,9 @@ int tsd_dist_finalize(tsd_ctx* ctx);
 int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
                          int iters, float* ms);
 
+/* Same for the fused attention core: Q,K [B][S][H*d], V^T [B][H*d][Sk]. */
+int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int iters, float* ms);
+
 /* ---- census -------------------------------------------------------------------------- */
 /* Algorithmic GFLOP (2*MAC of conv + linear + attention core) of one forward per sample
  * (SURVEY.md Appendix B): kind, latent side L, context tokens T. */

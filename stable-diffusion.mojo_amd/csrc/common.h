@@ -52,7 +52,7 @@ struct tsd_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Arena arena;
-  half_t* zeros = nullptr;  // 4 KiB of zeros: source for padded im2col taps / padded head dims
+  half_t* zeros = nullptr;  // 4 KiB: [0,2048) zeros (padded im2col taps / head dims); [2048,2176) fp16 ones
   void* staging = nullptr;  // device staging for host<->device copies
   size_t staging_cap = 0;
   void* rccl_comm = nullptr;

@@ -86,7 +86,8 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
 }
 
 // `Unet_Attention_Block.forward` diffusion.mojo:112-147 on NHWC tokens
-int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out) {
+int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out,
+                const CtxKV* pre) {
   const int C = w.C, B = x.B, S = x.H * x.W, d = w.n_embed, Hh = w.n_head;
   const int64_t M = (int64_t)B * S;
   if (C % 64 || x.C != C) TSD_FAIL(TSD_E_SHAPE, "attention block: C=%d (input %d) unsupported", C, x.C);
@@ -132,9 +133,12 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   half_t* q = qk;  // reuse
   a.p0 = ln;
   TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C));
-  half_t* kc = arena_alloc<half_t>(ctx, (int64_t)B * Tp * C); CHECK_ALLOC(kc);
-  half_t* vtc = arena_alloc<half_t>(ctx, (int64_t)B * C * Tp); CHECK_ALLOC(vtc);
-  {
+  CtxKV kv;
+  if (pre) kv = *pre;  // context K / V^T of all nine blocks were projected in two batched GEMMs (g_unet_forward)
+  else {
+    half_t* kc = arena_alloc<half_t>(ctx, (int64_t)B * Tp * C); CHECK_ALLOC(kc);
+    half_t* vtc = arena_alloc<half_t>(ctx, (int64_t)B * C * Tp); CHECK_ALLOC(vtc);
+    kv.K = kc; kv.ldk = C; kv.sK = (int64_t)Tp * C; kv.Vt = vtc; kv.ldvt = Tp; kv.sVt = (int64_t)C * Tp;
     GemmArgs g;  // K_c[b] = ctx_b . W_k^T -> [B][Tp][C]
     g.A0 = ctx16; g.lda0 = w.ca_k.Kpad; g.sA = (int64_t)Tp * w.ca_k.Kpad;
     g.Wt = w.ca_k.w; g.ldw = w.ca_k.Kpad;
@@ -149,8 +153,8 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     TSD_TRY(launch_gemm(ctx, v));
   }
   fa.Q = q; fa.ldq = C; fa.sQ = (int64_t)S * C;
-  fa.K = kc; fa.ldk = C; fa.sK = (int64_t)Tp * C;
-  fa.Vt = vtc; fa.ldvt = Tp; fa.sVt = (int64_t)C * Tp;
+  fa.K = kv.K; fa.ldk = kv.ldk; fa.sK = kv.sK;
+  fa.Vt = kv.Vt; fa.ldvt = kv.ldvt; fa.sVt = kv.sVt;
   fa.Sk = T;
   TSD_TRY(launch_flash_attention(ctx, fa));
   half_t* tok3 = tok;  // tok (first residual) is dead after tok2 was produced
@@ -274,9 +278,30 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
     TSD_TRY(alloc_out(i, ups ? side_in * 2 : side_in, w.cout));
     return g_resblock(ctx, src, B, side_in, side_in, ups, w, tvec, tld, a[i]);
   };
+  // context K and V^T projections of all nine attention blocks in two GEMMs (helpers/attention.mojo:102-103;
+  // the k_proj / v_proj weights are contiguous in the blob): K_all [B*Tp][6720], V^T_all [B][6720][Tp]
+  const int CK = u.kproj_all.N;
+  half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
+  half_t* vtc_all = arena_alloc<half_t>(ctx, (int64_t)B * CK * Tp); CHECK_ALLOC(vtc_all);
+  {
+    GemmArgs g;
+    g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
+    g.M = B * Tp; g.N = CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
+    TSD_TRY(launch_gemm(ctx, g));
+    GemmArgs v;
+    v.A0 = u.vproj_all.w; v.lda0 = u.vproj_all.Kpad; v.sA = 0;
+    v.Wt = ctx16; v.ldw = u.vproj_all.Kpad; v.sW = (int64_t)Tp * u.vproj_all.Kpad;
+    v.M = CK; v.N = Tp; v.K = u.vproj_all.Kpad; v.batch = B;
+    v.C = vtc_all; v.ldc = Tp; v.sC = (int64_t)CK * Tp;
+    TSD_TRY(launch_gemm(ctx, v));
+  }
   auto attn = [&](int i) -> int {
     TSD_TRY(alloc_out(i, a[i - 1].H, a[i - 1].C));
-    return g_unet_attn(ctx, a[i - 1], u.attn[i - 1], ctx16, T, Tp, a[i]);
+    const AttnW& w = u.attn[i - 1];
+    CtxKV kv;
+    kv.K = kc_all + w.kv_off; kv.ldk = CK; kv.sK = (int64_t)Tp * CK;
+    kv.Vt = vtc_all + (int64_t)w.kv_off * Tp; kv.ldvt = Tp; kv.sVt = (int64_t)CK * Tp;
+    return g_unet_attn(ctx, a[i - 1], w, ctx16, T, Tp, a[i], &kv);
   };
   // encoders (diffusion.mojo:236-250)
   TSD_TRY(alloc_out(1, L, 320));

@@ -22,7 +22,12 @@ int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw,
 
 int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
                int tld, Act out);
-int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out);
+struct CtxKV {  // projected context keys (token-major) and values (channel-major) of one attention block
+  const half_t* K = nullptr; int ldk = 0; int64_t sK = 0;
+  const half_t* Vt = nullptr; int ldvt = 0; int64_t sVt = 0;
+};
+int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out,
+                const CtxKV* pre = nullptr);
 int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act out);
 int g_attn_core(tsd_ctx* ctx, const AttnArgs& fa);
 int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& in_proj, half_t* qk, half_t* vt, int Sp);

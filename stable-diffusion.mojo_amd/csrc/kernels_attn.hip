@@ -20,14 +20,17 @@
 //   * head dims that are not a multiple of 16 (d=40) are zero-padded per 16-B chunk by pointing the
 //     DMA source at a zero page; LDS row pitches are odd multiples of 16 B (K) / XOR-swizzled (V^T)
 //     so all ds_read_b128 are bank-conflict-free.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct AttnK {
-  const half_t* Q; const half_t* K; const half_t* Vt; half_t* O; const half_t* zeros;
+  const half_t* Q; const half_t* K; const half_t* Vt; half_t* O; const half_t* zeros; const half_t* ones;
   long long sQ, sK, sVt, sO;
   int ldq, ldk, ldvt, ldo;
   int H, Sq, Sk, Skv;  // Skv: number of valid V^T columns (Sk rounded up to 8)
@@ -39,19 +42,30 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int D>
+template <int D, int NST>
 // min 2 waves/SIMD: caps the budget at 256 unified registers so the MFMA results stay in VGPRs (no v_accvgpr moves
 // around the softmax / rescale VALU work).
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   constexpr int DCH = D / 8;               // 16-B chunks per K row
   constexpr int KSTEPS = (DCH + 1) / 2;    // QK^T k-steps (16 wide)
-  constexpr int KPITCH = (2 * KSTEPS) | 1; // LDS pitch of a K row in chunks (odd -> conflict-free)
+  // LDS pitch of a K row in 16-B chunks: odd -> conflict-free ds_read_b128.  d=40: the 5 data chunks already are an odd
+  // pitch; its 6th (zero-padded) k-chunk then reads the next row's first chunk, which is harmless because the matching
+  // Q chunk is zero and every byte it can touch is finite tile data (the V^T tile follows the K tile).
+  constexpr int KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1);
   constexpr int DBLK = (D + 31) / 32;      // 32-wide d blocks of the output
   constexpr int VROWS = DBLK * 32;
   constexpr int K_BYTES = 64 * KPITCH * 16, V_BYTES = VROWS * 128;
-  constexpr int K_INSTR = KPITCH, V_INSTR = VROWS / 8;  // 1-KiB wave instructions per tile
+  // 1-KiB DMA wave-instructions per tile.  Only rows < D of the V^T tile are streamed: the pad rows (zeros, and the
+  // ones row) never change and are written once in the prologue.
+  static_assert(D % 8 == 0, "head dim");
+  constexpr int K_INSTR = KPITCH, V_INSTR = D / 8;
   constexpr int K_PW = (K_INSTR + 3) / 4, V_PW = (V_INSTR + 3) / 4;
   constexpr int BUF_BYTES = K_BYTES + V_BYTES;
+  // Row sums for free: when the 32-row d blocks have a spare row (d = 40, 80) V^T row D is all ones, so the P.V MFMA
+  // also accumulates l = sum_k P[q][k] in O^T row D - rescaled with O, and summed over the SAME fp16-rounded P.
+  constexpr bool ONES_ROW = VROWS > D;
+  constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3);  // accumulator holding row D (lanes hi=0)
+  static_assert(!ONES_ROW || (((D % 32) >> 2) & 1) == 0, "row D must live in the hi=0 half");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     k_data[i] = pos < DCH;
   }
   // V^T tile: LDS row R (= channel within head) x 8 chunks; phys pos holds logical chunk pos ^ ((R>>1)&7)
-  int v_chunk[V_PW]; long long v_off[V_PW]; bool v_data[V_PW];
+  int v_chunk[V_PW]; long long v_off[V_PW]; bool v_data[V_PW]; bool v_one[V_PW];
 #pragma unroll
   for (int i = 0; i < V_PW; i++) {
     const int R = (wave + 4 * i) * 8 + (lane >> 3);
@@ -99,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     v_chunk[i] = c;
     v_off[i] = (long long)R * p.ldvt + c * 8;
     v_data[i] = R < D;
+    v_one[i] = ONES_ROW && R == D;
   }
   const half_t* zsrc = p.zeros;
 
@@ -126,6 +141,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     }
   };
 
+  // constant part of both V^T buffers: rows D..VROWS (zero; row D = ones when it carries the row sums)
+  for (int i = tid; i < NST * (VROWS - D) * 8; i += 256) {
+    const int buf = i / ((VROWS - D) * 8), rem = i - buf * (VROWS - D) * 8;
+    const int R = D + (rem >> 3), pos = rem & 7;
+    const half_t fill = (ONES_ROW && R == D) ? (half_t)1.f : (half_t)0.f;
+    *(h8*)(smem + buf * BUF_BYTES + K_BYTES + R * 128 + pos * 16) = h8{fill, fill, fill, fill, fill, fill, fill, fill};
+  }
+
   f16v o[DBLK];
 #pragma unroll
   for (int d = 0; d < DBLK; d++)
@@ -136,26 +159,43 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   const int vkey = (lane >> 1) & 7;  // swizzle key of V^T row (db*32 + l31)
   const int ntiles = (p.Sk + 63) >> 6;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = 0; t < ntiles; t++) {
-    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-    const char* sK = smem + (t & 1) * BUF_BYTES;
-    const char* sV = sK + K_BYTES;
-
-    // ---- S^T = K . Q^T : two 32-key blocks ------------------------------------------------------
-    f16v s[2];
+  // S^T = K . Q^T of one 64-key tile: two 32-key blocks
+  auto qk = [&](int buf, f16v& s0, f16v& s1) {
+    const char* sK = smem + buf * BUF_BYTES;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
+    for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++) {
-        const h8 kf = *(const h8*)(sK + ((kb * 32 + l31) * KPITCH + ks * 2 + hi) * 16);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
-      }
+    for (int ks = 0; ks < KSTEPS; ks++) {
+      const h8 k0f = *(const h8*)(sK + ((l31)*KPITCH + ks * 2 + hi) * 16);
+      const h8 k1f = *(const h8*)(sK + ((32 + l31) * KPITCH + ks * 2 + hi) * 16);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0f, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1f, qf[ks], s1, 0, 0, 0);
     }
+  };
+
+  f16v sA[2], sB[2];  // score tiles: current and (NST == 3) the next one, ping-ponged by a 2x unrolled loop
+  int cur = 0;        // ring slot of tile t
+  if (NST == 2) {
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    stage(0, 0);
+    if (ntiles > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    qk(0, sA[0], sA[1]);
+  }
+  // one tile: [NST==3: issue the NEXT tile's QK^T MFMAs first so they run under this tile's softmax VALU work]
+  auto tile = [&](int t, f16v (&s)[2], f16v (&sn)[2]) {
+    if (NST == 2) {
+      if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+      qk(t & 1, s[0], s[1]);
+    } else {
+      if (t + 2 < ntiles) stage(t + 2, cur >= 1 ? cur - 1 : 2);  // slot of tile t-1 (free since the last barrier)
+      if (t + 1 < ntiles) qk(cur == 2 ? 0 : cur + 1, sn[0], sn[1]);
+    }
+    const char* sV = smem + (NST == 2 ? (t & 1) : cur) * BUF_BYTES + K_BYTES;
     // lane (hi, r) of block kb holds key kb*32 + (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
     if ((t + 1) * 64 > p.Sk) {
       const int k0 = t * 64;
@@ -174,25 +214,37 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-    const float mc = m_new * p.c;
-    m_run = m_new;
-    float psum = 0.f;
+    if (__any(mx > m_run)) {  // wave-uniform: rescale only when some row's running max actually grew
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      m_run = m_new;
+      if (!ONES_ROW) l_run *= alpha;
+      const f2 a2 = {alpha, alpha};
+#pragma unroll
+      for (int d = 0; d < DBLK; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f2 v = {o[d][r], o[d][r + 1]};
+          v *= a2;
+          o[d][r] = v[0]; o[d][r + 1] = v[1];
+        }
+    }
+    const float nmc = -m_run * p.c;
+    const f2 c2 = {p.c, p.c}, m2 = {nmc, nmc};
+    f2 psum2 = {0.f, 0.f};
     h8 pf[4];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb][r] * p.c - mc);
-        psum += pv;
-        pf[kb * 2 + (r >> 3)][r & 7] = (half_t)pv;
+      for (int r = 0; r < 16; r += 2) {
+        f2 e = {s[kb][r], s[kb][r + 1]};
+        e = e * c2 + m2;  // v_pk_fma_f32
+        const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+        if (!ONES_ROW) psum2 += f2{p0, p1};
+        pf[kb * 2 + (r >> 3)][r & 7] = (half_t)p0;
+        pf[kb * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < DBLK; d++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) o[d][r] *= alpha;
+    if (!ONES_ROW) l_run += psum2[0] + psum2[1];
     // ---- O^T += V^T . P^T ------------------------------------------------------------------------
 #pragma unroll
     for (int d = 0; d < DBLK; d++) {
@@ -204,10 +256,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    cur = (cur == 2) ? 0 : cur + 1;
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(t, sA, sB);
+    if (t + 1 < ntiles) tile(t + 1, sB, sA);
   }
 
   // ---- normalise and store O[b][q][h*D + d] -----------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  if (ONES_ROW) {  // row D of O^T = sum of P; it sits in the hi=0 lane of each query's lane pair
+    const float lv = o[L_BLK][L_REG];
+    const float lo = __shfl_xor(lv, 32);
+    l_tot = hi ? lo : lv;
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
   const float inv = 1.f / l_tot;
   const int qrow = q0 + l31;
   if (qrow < p.Sq) {
@@ -228,12 +292,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
 }
 
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
+static int g_attn_nst = 2;  // schedule: 2 = double buffer (default; measured faster), 3 = QK(t+1) issued under softmax(t) (TSD_ATTN_NST=3)
 
-template <int D>
+template <int D, int NST>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
-  constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (2 * KSTEPS) | 1, DBLK = (D + 31) / 32;
-  constexpr int LDS = 2 * (64 * KPITCH * 16 + DBLK * 32 * 128);
-  auto fn = flash_attn_kernel<D>;
+  constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
+  constexpr int LDS = NST * (64 * KPITCH * 16 + DBLK * 32 * 128);
+  auto fn = flash_attn_kernel<D, NST>;
   static bool attr = false;
   if (!attr) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -249,16 +314,57 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4) TSD_FAIL(TSD_E_SHAPE, "flash attention: misaligned pitches");
   if (a.Sq <= 0 || a.Sk <= 0) TSD_FAIL(TSD_E_SHAPE, "flash attention: empty sequence");
   if (!ctx->launch()) return TSD_OK;
+  {
+    static bool env_read = false;
+    if (!env_read) { const char* e = getenv("TSD_ATTN_NST"); if (e && (e[0] == '2' || e[0] == '3')) g_attn_nst = e[0] - '0'; env_read = true; }
+  }
   ProfScope prof(ctx, KC_ATTN, a.Sq, a.Sk, a.d, a.B * a.H);
   AttnK k;
-  k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros;
+  k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros; k.ones = ctx->zeros + 1024;
   k.sQ = a.sQ; k.sK = a.sK; k.sVt = a.sVt; k.sO = a.sO;
   k.ldq = a.ldq; k.ldk = a.ldk; k.ldvt = a.ldvt; k.ldo = a.ldo;
   k.H = a.H; k.Sq = a.Sq; k.Sk = a.Sk; k.Skv = std::min(round_up(a.Sk, 8), a.ldvt);
   k.c = a.scale * 1.4426950408889634f;
   switch (a.d) {
-    case 40: return launch_fa<40>(ctx, k, a.B, a.H, a.Sq);
-    case 80: return launch_fa<80>(ctx, k, a.B, a.H, a.Sq);
-    default: return launch_fa<160>(ctx, k, a.B, a.H, a.Sq);
+    case 40: return g_attn_nst == 2 ? launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq) : launch_fa<40, 3>(ctx, k, a.B, a.H, a.Sq);
+    case 80: return g_attn_nst == 2 ? launch_fa<80, 2>(ctx, k, a.B, a.H, a.Sq) : launch_fa<80, 3>(ctx, k, a.B, a.H, a.Sq);
+    default: return launch_fa<160, 2>(ctx, k, a.B, a.H, a.Sq);
   }
+}
+
+// Debug/bench entry: time `iters` launches of the fused attention core on synthetic device data.
+extern "C" int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int iters, float* ms) {
+  if (!ctx || !ms || iters <= 0) TSD_FAIL(TSD_E_ARG, "attn_bench: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int C = H * d, Skp = round_up(Sk, 8);
+  const int64_t nq = (int64_t)B * Sq * C, nk = (int64_t)B * Sk * C, nv = (int64_t)B * C * Skp;
+  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(2 * nq + nk + nv) * 2 + (size_t)std::max(nq, std::max(nk, nv)) * 4 + 8192));
+  ctx->arena.top = 0;
+  half_t* Q = arena_alloc<half_t>(ctx, nq);
+  half_t* K = arena_alloc<half_t>(ctx, nk);
+  half_t* Vt = arena_alloc<half_t>(ctx, nv);
+  half_t* O = arena_alloc<half_t>(ctx, nq);
+  float* tmp = arena_alloc<float>(ctx, std::max(nq, std::max(nk, nv)));
+  if (!Q || !K || !Vt || !O || !tmp) TSD_FAIL(TSD_E_ALLOC, "attn_bench: arena");
+  TSD_TRY(launch_fill_uniform(ctx, tmp, nq, 1, 11, 2.f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nq, Q, (int)nq, 1));
+  TSD_TRY(launch_fill_uniform(ctx, tmp, nk, 1, 12, 2.f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nk, K, (int)nk, 1));
+  TSD_TRY(launch_fill_uniform(ctx, tmp, nv, 1, 13, 1.f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nv, Vt, (int)nv, 1));
+  AttnArgs a;
+  a.Q = Q; a.ldq = C; a.sQ = (int64_t)Sq * C; a.K = K; a.ldk = C; a.sK = (int64_t)Sk * C;
+  a.Vt = Vt; a.ldvt = Skp; a.sVt = (int64_t)C * Skp; a.O = O; a.ldo = C; a.sO = (int64_t)Sq * C;
+  a.B = B; a.H = H; a.d = d; a.Sq = Sq; a.Sk = Sk; a.scale = 1.f / sqrtf((float)d);
+  int r = launch_flash_attention(ctx, a);
+  if (r != TSD_OK) return r;
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < iters && r == TSD_OK; i++) r = launch_flash_attention(ctx, a);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+  *ms = t / iters;
+  ctx->arena.top = 0;
+  return r;
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // CU with NS-1 K-tiles of DMA in flight behind counted s_waitcnt vmcnt (few-tile problems: M = 2048 level of the
 // UNet, where only 256 tiles exist and every iteration would otherwise expose a full HBM/L2 round trip).
 template <int WGM, int WGN, int FM, int FN, bool CONV, int NS>
-__global__ __launch_bounds__(WGM* WGN * 64, (NS <= 2 ? 2 : 1)) void gemm_kernel(const GemmK p) {
+__global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * FN <= 20 ? 2 : 1)) void gemm_kernel(const GemmK p) {
   constexpr int NW = WGM * WGN;
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int BMw = FM * 16, BNw = FN * 16;
@@ -214,8 +214,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NS <= 2 ? 2 : 1)) void gemm_kernel(
   };
 
   const int nk = p.K >> 6;
-  constexpr int LPS = A_PW + W_PW;  // DMA instructions per stage per wave (when evenly divisible)
-  static_assert(NS == 2 || (A_INSTR % NW == 0 && W_INSTR % NW == 0), "counted vmcnt needs equal loads per wave");
+  // DMA instructions per stage per wave: waves below the remainder issue one more (wave-uniform)
+  constexpr int LPS_HI = A_PW + W_PW;
+  constexpr int LPS_LO = (A_INSTR % NW ? A_PW - 1 : A_PW) + (W_INSTR % NW ? W_PW - 1 : W_PW);
+  static_assert(NS == 2 || A_INSTR % NW == 0, "A tile loads must divide evenly among the waves");
+  const bool lps_hi = (W_INSTR % NW == 0) || wave < (W_INSTR % NW);
 #pragma unroll
   for (int s = 0; s < NS - 1; s++)
     if (s < nk) stage(s, s);
@@ -223,8 +226,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NS <= 2 ? 2 : 1)) void gemm_kernel(
   for (int kt = 0; kt < nk; kt++) {
     // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
     const int ahead = min(NS - 2, nk - 1 - kt);
-    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * LPS>();
-    else if (NS >= 3 && ahead == 1) wait_vmcnt<LPS>();
+    if (NS >= 4 && ahead >= 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
+    else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
     asm volatile("" ::: "memory");
@@ -349,7 +352,10 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //   8  128x128   3       96 KiB
 //   9   64x128   4       96 KiB
 //  10   64x128   3       72 KiB
-constexpr int N_GEMM_CFG = 11;
+//  11  256x160   3      156 KiB   8 waves, 1 block/CU, two K-tiles of DMA in flight
+//  12  256x160   2      104 KiB   8 waves
+//  13  256x128   3      144 KiB   8 waves
+constexpr int N_GEMM_CFG = 16;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 template <bool CONV>
@@ -366,6 +372,11 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 8: return launch_cfg<2, 2, 4, 4, CONV, 3>(ctx, k, batch);
     case 9: return launch_cfg<2, 2, 2, 4, CONV, 4>(ctx, k, batch);
     case 10: return launch_cfg<2, 2, 2, 4, CONV, 3>(ctx, k, batch);
+    case 11: return launch_cfg<4, 2, 4, 5, CONV, 3>(ctx, k, batch);
+    case 12: return launch_cfg<4, 2, 4, 5, CONV, 2>(ctx, k, batch);
+    case 13: return launch_cfg<4, 2, 4, 4, CONV, 3>(ctx, k, batch);
+    case 14: return launch_cfg<2, 2, 8, 5, CONV, 3>(ctx, k, batch);
+    case 15: return launch_cfg<2, 2, 8, 5, CONV, 2>(ctx, k, batch);
     default: TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
   }
 }

@@ -5,9 +5,9 @@
 // Formula kept literal (App.A D12): y = (x - mu) / (sigma + eps) * gamma, population sigma,
 // eps added to sigma, scalar gamma, no beta.
 //
-// GroupNorm is three launches: per-slab partial (sum, sumsq) over full NHWC pixel rows (coalesced
-// 16-B loads, 4 in flight per thread, fp32 accumulation, deterministic - no atomics), a tiny finalize
-// (statistics finished in double), then an apply pass that streams the tensor once.  The source may be the channel-concat
+// GroupNorm is two launches: per-slab partial (sum, sumsq) over full NHWC pixel rows (coalesced 16-B loads,
+// 4 in flight per thread, fp32 accumulation, deterministic - no atomics), then an apply pass whose blocks each
+// finish the statistics in double from the <= 64 slab partials and stream the tensor once.  The source may be the channel-concat
 // of two tensors (UNet skip connections, diffusion.mojo:253-270) so the concat is never
 // materialised for the normalised branch.
 #include "common.h"
@@ -109,37 +109,37 @@ __global__ __launch_bounds__(256) void k_gn_partial(const GnK p) {
   }
 }
 
-// one wave per (sample, group): lanes stride over the slabs, fixed-order butterfly in double (deterministic)
-__global__ __launch_bounds__(256) void k_gn_finalize(const GnK p, int total) {
-  const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);  // b * G + g
-  if (idx >= total) return;
-  const int b = idx / p.G, g = idx - b * p.G;
-  double t1 = 0.0, t2 = 0.0;
-  for (int s = lane; s < p.nslab; s += 64) {
-    const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
-    t1 += (double)o[0];
-    t2 += (double)o[1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    t1 += __shfl_xor(t1, o);
-    t2 += __shfl_xor(t2, o);
-  }
-  if (lane == 0) {
-    const double n = (double)p.cpg * (double)p.HW;
-    const double mu = t1 / n;
-    double var = t2 / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    float* st = p.stats + (int64_t)idx * 2;
-    st[0] = (float)mu;
-    st[1] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));  // eps added to sigma (helpers/utils.mojo:1871-1873)
-  }
-}
-
 __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gn[];
+  float* st = (float*)smem_gn;  // [G][2] (mean, gamma/(sigma+eps))
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
+  // every block finishes the statistics itself (a few KB of partials from L2) - no separate finalize launch.
+  // 8 lanes per group stride over the slabs; fixed-order butterfly in double => deterministic.
+  for (int g0 = 0; g0 < p.G; g0 += 32) {
+    const int g = g0 + (tid >> 3), sl = tid & 7;
+    double t1 = 0.0, t2 = 0.0;
+    if (g < p.G)
+      for (int s = sl; s < p.nslab; s += 8) {
+        const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
+        t1 += (double)o[0];
+        t2 += (double)o[1];
+      }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      t1 += __shfl_xor(t1, o);
+      t2 += __shfl_xor(t2, o);
+    }
+    if (g < p.G && sl == 0) {
+      const double n = (double)p.cpg * (double)p.HW;
+      const double mu = t1 / n;
+      double var = t2 / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      st[2 * g] = (float)mu;
+      st[2 * g + 1] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));  // eps added to sigma (helpers/utils.mojo:1871-1873)
+    }
+  }
+  __syncthreads();
   const GnMap m = gn_map(p.C, tid);
   if (!m.active) return;
   float mu[GN_MAX_CPT][8], ri[GN_MAX_CPT][8];
@@ -149,9 +149,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int g = ch < m.nch ? (ch * 8 + j) / p.cpg : 0;
-      const float* st = p.stats + ((int64_t)b * p.G + g) * 2;
-      mu[q][j] = st[0];
-      ri[q][j] = st[1];
+      mu[q][j] = st[2 * g];
+      ri[q][j] = st[2 * g + 1];
     }
   }
   const int p_begin = blockIdx.x * p.apply_pixels;
@@ -197,9 +196,9 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   k.cpg = C / groups;
   const int nch = C / 8, PL = nch <= 256 ? 256 / nch : 1;
   // stats pass: 2*GN_UNROLL pixels per thread, at most 512 slabs per sample ; apply pass: GN_UNROLL pixels per thread
-  k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 512));
+  k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 64));  // <= 64 slabs: every apply block re-reduces them
   k.nslab = ceil_div(HW, k.slab_pixels);
-  k.apply_pixels = GN_UNROLL * PL;
+  k.apply_pixels = 2 * GN_UNROLL * PL;
   k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
   k.stats = arena_alloc<float>(ctx, (int64_t)B * groups * 2);
   if (!k.partial || !k.stats) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
@@ -208,9 +207,8 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   ProfScope prof(ctx, KC_GROUPNORM);
   hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(B * groups, 4)), dim3(256), 0, ctx->stream, k, B * groups);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), 0, ctx->stream, k);
+  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
+                     ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

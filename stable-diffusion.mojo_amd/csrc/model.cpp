@@ -31,6 +31,10 @@ extern "C" int tsd_model_create(tsd_ctx* ctx, int kind, tsd_model** out) {
     o = (o + 255) & ~size_t(255);
     for (auto& p : m->params) if (p.region == 2) { p.off = o; o += p.bytes; }
     o = (o + 255) & ~size_t(255);
+    for (auto& p : m->params) if (p.region == 3) { p.off = o; o += p.bytes; }
+    o = (o + 255) & ~size_t(255);
+    for (auto& p : m->params) if (p.region == 4) { p.off = o; o += p.bytes; }
+    o = (o + 255) & ~size_t(255);
     for (auto& p : m->params) if (p.region == 0) { p.off = o; o += p.bytes; o = (o + 255) & ~size_t(255); }
     off = o;
   }
@@ -168,7 +172,7 @@ int model_resolve(tsd_model* m) {
     UNetW& u = m->unet;
     u.t1 = model_lin(m, "time_embed.layer1", true);
     u.t2 = model_lin(m, "time_embed.layer2", true);
-    int toff = 0;
+    int toff = 0, kvoff = 0;
     bool first = true;
     for (int i = 0; i < 23; i++) {
       const LayerDef& l = UNET_LAYERS[i];
@@ -196,9 +200,13 @@ int model_resolve(tsd_model* m) {
         a.geglu1 = model_lin(m, n + ".layer8", true);
         a.geglu2 = model_lin(m, n + ".layer9", true);
         a.conv_out = model_conv(m, n + ".layer10");
+        a.kv_off = kvoff;
+        if (kvoff == 0) { u.kproj_all = a.ca_k; u.vproj_all = a.ca_v; }
+        kvoff += a.C;
       }
     }
     u.tproj.N = toff;  // 6720 rows: the nine layer3 weights are contiguous in the blob
+    u.kproj_all.N = kvoff; u.vproj_all.N = kvoff;  // 6720 rows each
     u.conv1 = model_conv(m, "unet.layer1");
     u.conv4 = model_conv(m, "unet.layer4");
     u.conv7 = model_conv(m, "unet.layer7");

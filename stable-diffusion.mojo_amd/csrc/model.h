@@ -18,7 +18,7 @@ struct ParamSpec {
   // packing
   int Opad = 0, Kpad = 0;  // conv: Opad rows, Kpad = Ipad ; linear: Kpad
   int interleave = 0;      // GEGLU (a,g) row interleave (diffusion.mojo:138-141)
-  int region = 0;          // 0 normal, 1 time-projection weights, 2 time-projection biases (kept contiguous)
+  int region = 0;          // 0 normal; dense contiguous tables: 1 time-proj weights, 2 time-proj biases, 3 k_proj, 4 v_proj
   size_t off = 0, bytes = 0;
   int64_t numel() const {
     int64_t n = 1;
@@ -47,6 +47,7 @@ struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   int n_head = 0, n_embed = 0, C = 0, d_ctx = 768;
   ConvW conv_in, conv_out;
   LinW sa_in, sa_out, ca_q, ca_k, ca_v, ca_out, geglu1, geglu2;
+  int kv_off = 0;  // row offset of this block in the concatenated k_proj / v_proj tables
 };
 struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;
@@ -56,6 +57,7 @@ struct VaeAttnW {  // vae.mojo:9-11
 struct UNetW {
   LinW t1, t2;       // Time_Embedding
   LinW tproj;        // concatenated layer3 of the 9 residual blocks: [6720][1280]
+  LinW kproj_all, vproj_all;  // concatenated cross-attention k_proj / v_proj of the 9 attention blocks: [6720][768]
   ConvW conv1, conv4, conv7, final_conv;
   ResW res[23];
   AttnW attn[23];

@@ -51,11 +51,11 @@ struct Builder {
     ParamSpec w;
     w.name = name + ".weight"; w.ndim = 2; w.shape[0] = fout; w.shape[1] = fin; w.kind = P_LIN_W; w.used = used;
     w.bound = (float)(1.0 / sqrt((double)fin));  // App.A D18 (1/sqrt(fan_in), not the literal in^-1/4)
-    w.Kpad = round_up(fin, 64); w.Opad = fout; w.interleave = interleave; w.region = region ? 1 : 0;
+    w.Kpad = round_up(fin, 64); w.Opad = fout; w.interleave = interleave; w.region = region;
     out.push_back(w);
     ParamSpec b;
     b.name = name + ".bias"; b.ndim = 1; b.shape[0] = fout; b.kind = P_LIN_B; b.used = used && use_bias;
-    b.bound = w.bound; b.Opad = fout; b.interleave = interleave; b.region = region ? 2 : 0;
+    b.bound = w.bound; b.Opad = fout; b.interleave = interleave; b.region = region == 1 ? 2 : 0;
     out.push_back(b);
   }
   void unet_res(const std::string& n, int cin, int cout) {  // diffusion.mojo:34-42
@@ -70,8 +70,8 @@ struct Builder {
     lin(n + ".layer4.in_proj", C, 3 * C, false);
     lin(n + ".layer4.out_proj", C, C);
     lin(n + ".layer6.q_proj", C, C, false);
-    lin(n + ".layer6.k_proj", dctx, C, false);
-    lin(n + ".layer6.v_proj", dctx, C, false);
+    lin(n + ".layer6.k_proj", dctx, C, false, true, 0, 3);
+    lin(n + ".layer6.v_proj", dctx, C, false, true, 0, 4);
     lin(n + ".layer6.out_proj", C, C);
     lin(n + ".layer8", C, 8 * C, true, true, 1);
     lin(n + ".layer9", 4 * C, C);

@@ -42,6 +42,7 @@ extern "C" int tsd_ctx_create(int device, tsd_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipMalloc((void**)&c->zeros, 4096));
   HIP_TRY(hipMemsetAsync(c->zeros, 0, 4096, c->stream));
+  HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)(c->zeros + 1024), 0x3C00, 64, c->stream));  // 64 halves of 1.0 (attention row sums)
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = c;
   return TSD_OK;
