@@ -62,6 +62,25 @@ def broadcast_weights(models, rank, world, local_rank):
     return time.time() - t0, nbytes
 
 
+def pmc_traffic_per_gemm_launch():
+    """HBM bytes per gemm_kernel launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes over this same command, scripts/gpu_pmc_bench.sh -> profiles/r01_pmc_hbm_traffic.txt), with the
+    gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads -> x2).  None when the
+    profile is absent: bench.py itself never runs a profiler."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.txt")
+    try:
+        fetch = write = launches = 0.0
+        for line in open(path).read().splitlines()[1:]:
+            parts = line.split()
+            if "gemm_kernel" not in line or len(parts) < 4:
+                continue
+            n, f, w = float(parts[-3]), float(parts[-2]), float(parts[-1])  # dispatches, KiB/dispatch, KiB/dispatch
+            fetch += n * f; write += n * w; launches += n
+        return None if launches == 0 else int((2.0 * fetch + write) * 1024 / launches)
+    except OSError:
+        return None
+
+
 def cpu_baseline(L, T):
     """The oracle (numpy restatement of the reference's algorithm - 'port') timed on this box's host cores on a
     bounded sample: ONE sample-step (1/8 of a batch-8 step: one Diffusion.forward + DDPM update at L=64)."""
@@ -180,7 +199,7 @@ def main():
         achieved = (gemm_gf * B / 1e3) / (gemm_ms / 1e3) if gemm_ms > 0 else 0.0  # TFLOP/s
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<...> (dense + conv3x3 implicit GEMM)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": pmc_traffic_per_gemm_launch(),
                     "launches_per_step": gemm_launches, "avg_launch_us": round(1e3 * gemm_ms / max(1, gemm_launches), 2),
                     "algorithmic_gflop_per_step": round(gemm_gf * B, 1),
                     "per_class_ms_per_step": {k: round(v[0], 4) for k, v in per_step.items()},

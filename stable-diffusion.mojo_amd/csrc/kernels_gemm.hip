@@ -18,6 +18,8 @@
 //     round trip), 128-B rows XOR-swizzled by (row & 7) on the source side so every
 //     ds_read_b128 fragment read is bank-conflict-free; double-buffered, one barrier per K-tile.
 //   * XCD-aware bijective block remap so tiles sharing an A panel hit the same per-XCD L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -329,6 +331,12 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
+    if (getenv("TSD_DEBUG_OCC")) {
+      int nb = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, WGM * WGN * 64, LDS);
+      fprintf(stderr, "[occ] gemm<%d,%d,%d,%d,%d,%d> LDS=%d blocks/CU=%d (%s)\n", WGM, WGN, FM, FN, (int)CONV, NS, LDS, nb,
+              hipGetErrorString(e));
+    }
   }
   GemmK kk = k;
   kk.tiles_n = ceil_div(k.N, BN);

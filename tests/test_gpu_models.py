@@ -172,3 +172,65 @@ def test_per_struct_composition_equals_fused_module(gpu_ctx, tsd_mod, unet_param
     out = fin.forward(u.forward(lat[0], ctx[0], te.forward(t320)))
     ref = models.diffusion(P, lat[0], ctx[0], ops.time_embedding(700.0))
     assert_close(out, ref, TOL_MODEL, None, "per-struct UNet composition")
+
+
+# ---- BASELINE.json configs at full size ------------------------------------------------------------------
+def test_config1_256px_10_steps_matches_oracle(gpu_ctx, tsd_mod, diffusion, decoder, unet_params, dec_params):
+    """BASELINE configs[0]: Tiny-SD 256x256 (latent 32), 1 prompt, 10 DDPM steps, random-init weights - the whole
+    loop + decode on the GPU against the CPU oracle (the reference's own CPU-runnable configuration)."""
+    B, L, steps = 1, 32, 10
+    lat, ctx = _inputs(B, L, tag=700)
+    noise = rng.normal(SEED, 702, steps * B * 4 * L * L).reshape(steps, B, 4, L, L)
+    s = tsd_mod.Session(diffusion.model, decoder.model, B, L, 77, cfg=False)
+    s.set_schedule(1000, steps, 0)
+    assert [s.timestep(i) for i in range(steps)] == [900, 800, 700, 600, 500, 400, 300, 200, 100, 0]
+    s.upload(lat, ctx, None, noise)
+    for i in range(steps):
+        s.step(i)
+    got_lat = s.latents()
+    s.decode()
+    got_img = s.images(rescale=True)
+    s.close()
+    ref_lat = sampler.denoise(unet_params, lat[0], ctx[0], steps, noise[:, 0])[None]
+    assert_close(got_lat, ref_lat, TOL_MODEL, None, "config1: 10-step denoise L=32")
+    ref_img = ops.rescale_to_u8_range(models.decoder(dec_params, got_lat[0]))[None]  # decode the SAME latents
+    assert got_img.shape == (1, 3, 256, 256) and got_img.min() >= 0 and got_img.max() <= 255
+    err = float(np.abs(got_img - ref_img).mean())
+    print(f"[parity] config1 decoded image: mean |err| = {err:.3f} on the 0..255 scale")
+    assert err < 1.0
+
+
+def test_headline_size_properties(gpu_ctx, tsd_mod, diffusion):
+    """BASELINE configs[1] size (latent 64, batch 8): size-independent properties - run-to-run determinism and
+    batch invariance are BITWISE (nothing couples samples; no atomics anywhere on the path), outputs finite."""
+    B, L = 8, 64
+    lat, ctx = _inputs(B, L, tag=710)
+    temb = np.stack([tsd_mod.get_time_embedding(float(t)).reshape(320) for t in (980, 960, 700, 500, 300, 100, 20, 0)])
+    a = diffusion.forward(lat, ctx, temb)
+    b = diffusion.forward(lat, ctx, temb)
+    assert np.isfinite(a).all() and a.shape == (B, 4, L, L)
+    np.testing.assert_array_equal(a, b)
+    for i in (0, 5):
+        np.testing.assert_array_equal(diffusion.forward(lat[i], ctx[i], temb[i]), a[i])
+    # a permutation of the batch permutes the outputs
+    perm = np.array([3, 1, 7, 0, 2, 6, 5, 4])
+    np.testing.assert_array_equal(diffusion.forward(lat[perm], ctx[perm], temb[perm]), a[perm])
+
+
+def test_decoder_512px_properties(gpu_ctx, tsd_mod, decoder):
+    """Decoder at the 512x512 size (latent 64): finite, deterministic, batch-invariant (bitwise)."""
+    lat = rng.normal(SEED, 720, 2 * 4 * 64 * 64).reshape(2, 4, 64, 64) * 0.18215
+    a = decoder.forward(lat)
+    assert a.shape == (2, 3, 512, 512) and np.isfinite(a).all()
+    np.testing.assert_array_equal(decoder.forward(lat[1]), a[1])
+
+
+def test_conv_linearity_at_full_size(gpu_ctx, tsd_mod):
+    """conv(x + y) == conv(x) + conv(y) (zero bias) at the 320-channel 64x64 size, within fp16 rounding."""
+    from util import randn, uni
+    x, y = randn(730, 320, 64, 64), randn(731, 320, 64, 64)
+    c = tsd_mod.Conv2D(320, 320, 3, (1, 1))
+    c.kernel = uni(732, 1.0 / np.sqrt(2880), 320, 320, 3, 3)
+    lhs = c.forward(x + y)
+    rhs = c.forward(x) + c.forward(y)
+    assert rel_l2(lhs, rhs) < 2e-3
