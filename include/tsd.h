@@ -230,6 +230,9 @@ int tsd_dist_finalize(tsd_ctx* ctx);
 int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
                          int iters, float* ms);
 
+/* Run one problem with tile configuration `cfg` and with `ref_cfg`; max |difference| and max |reference|. */
+int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
+                         int ref_cfg, float* max_abs_diff, float* max_abs_ref);
 /* Same for the fused attention core: Q,K [B][S][H*d], V^T [B][H*d][Sk]. */
 int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int iters, float* ms);
 

@@ -321,7 +321,8 @@ int launch_fill_uniform(tsd_ctx* ctx, float* dst, int64_t n, uint64_t seed, uint
 
 // ---- weight packing ------------------------------------------------------------------------------
 // conv (O,I,k,k) fp32 -> fp16 [Opad][k*k][Ipad]: K index = tap*Ipad + i (tap-major so a 64-wide
-// K chunk stays inside one tap and reads 128 contiguous NHWC bytes).
+// K chunk stays inside one tap and reads 128 contiguous NHWC bytes).  (Measured: making the taps the INNER K index
+// for L2 reuse of the input rows is slower - the per-tile tap address update costs more than the locality buys.)
 __global__ void k_pack_conv(const float* __restrict__ src, int O, int I, int kk, half_t* __restrict__ dst, int Ipad,
                             int64_t total) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

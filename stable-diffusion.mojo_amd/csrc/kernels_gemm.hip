@@ -18,6 +18,7 @@
 //     round trip), 128-B rows XOR-swizzled by (row & 7) on the source side so every
 //     ds_read_b128 fragment read is bank-conflict-free; double-buffered, one barrier per K-tile.
 //   * XCD-aware bijective block remap so tiles sharing an A panel hit the same per-XCD L2.
+#include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -58,7 +59,11 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // NS = LDS ring depth.  NS == 2: two blocks per CU hide the DMA latency by TLP (big M).  NS >= 3: one block per
 // CU with NS-1 K-tiles of DMA in flight behind counted s_waitcnt vmcnt (few-tile problems: M = 2048 level of the
 // UNet, where only 256 tiles exist and every iteration would otherwise expose a full HBM/L2 round trip).
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS>
+// PP ("ping-pong", 8 waves, NS == 3): waves 0-3 and 4-7 share the four SIMDs pairwise and run half an iteration apart -
+// while one group issues its 2*FM*FN MFMAs of K-tile t the other group reads its fragments of the next tile from LDS
+// and issues DMA, so each SIMD's matrix pipe always has a wave feeding it.  Two barriers per K-tile separate the
+// phases; K-tiles are DMA'd three ahead into a 3-slot ring behind counted s_waitcnt vmcnt.
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false>
 __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * FN <= 20 ? 2 : 1)) void gemm_kernel(const GemmK p) {
   constexpr int NW = WGM * WGN;
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
@@ -221,22 +226,95 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   constexpr int LPS_LO = (A_INSTR % NW ? A_PW - 1 : A_PW) + (W_INSTR % NW ? W_PW - 1 : W_PW);
   static_assert(NS == 2 || A_INSTR % NW == 0, "A tile loads must divide evenly among the waves");
   const bool lps_hi = (W_INSTR % NW == 0) || wave < (W_INSTR % NW);
+  if constexpr (!PP) {
+  #pragma unroll
+    for (int s = 0; s < NS - 1; s++)
+      if (s < nk) stage(s, s);
+    int cur = 0, nxt = NS - 1;  // ring slots of tile kt and tile kt+NS-1
+    for (int kt = 0; kt < nk; kt++) {
+      // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
+      const int ahead = min(NS - 2, nk - 1 - kt);
+      if (NS >= 4 && ahead >= 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
+      else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+      compute(cur);
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+  } else {
+    static_assert(!PP || (NW == 8 && NS == 3), "ping-pong schedule: 8 waves, 3-slot ring");
+    const bool grpB = wave >= 4;
+    h8 af[2][FM], wf[2][FN];
+    auto read_frags = [&](int buf) {
+      const char* sA = smem + buf * TILE_BYTES;
+      const char* sW = sA + BM * 128;
 #pragma unroll
-  for (int s = 0; s < NS - 1; s++)
-    if (s < nk) stage(s, s);
-  int cur = 0, nxt = NS - 1;  // ring slots of tile kt and tile kt+NS-1
-  for (int kt = 0; kt < nk; kt++) {
-    // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
-    const int ahead = min(NS - 2, nk - 1 - kt);
-    if (NS >= 4 && ahead >= 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
-    else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
-    asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
-    compute(cur);
-    cur = (cur + 1 == NS) ? 0 : cur + 1;
-    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      for (int kk = 0; kk < 2; kk++) {
+        const int coff = ((kk * 4 + cq) ^ key) << 4;
+#pragma unroll
+        for (int a = 0; a < FM; a++) af[kk][a] = *(const h8*)(sA + a_rd + a * 2048 + coff);
+#pragma unroll
+        for (int b = 0; b < FN; b++) wf[kk][b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
+      }
+    };
+    auto mfma_all = [&]() {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int a = 0; a < FM; a++)
+#pragma unroll
+          for (int b = 0; b < FN; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
+    };
+    // wait until at most `n` of this wave's most recent K-tiles are still in flight
+    auto wait_in_flight = [&](int n) {
+      if (n >= 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
+      else if (n == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
+      else wait_vmcnt<0>();
+    };
+    auto phase_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: tiles 0..2 in flight
+    const int npro = min(3, nk);
+    for (int s = 0; s < npro; s++) stage(s, s);
+    wait_in_flight(npro - 1);  // own share of tile 0 landed
+    phase_barrier();           // tile 0 complete in LDS
+    // Two specialised loops (same barrier count) so each group's fragment registers have one live range.
+    if (!grpB) {
+      read_frags(0);                       // "phase Y(-1)"
+      phase_barrier();
+      int slot = 0;
+      for (int t = 0; t < nk; t++) {
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        mfma_all();                                                   // X(t): multiply tile t (B reads tile t)
+        if (t + 1 < nk) wait_in_flight(t + 2 < nk ? 1 : 0);            // own share of tile t+1 landed
+        phase_barrier();                                              // B1(t): slot of tile t free, tile t+1 complete
+        if (t + 3 < nk) stage(t + 3, slot);                           // Y(t): refill, then pick up tile t+1
+        if (t + 1 < nk) read_frags(slot1);
+        phase_barrier();                                              // B2(t)
+        slot = slot1;
+      }
+    } else {
+      phase_barrier();
+      int slot = 0;
+      for (int t = 0; t < nk; t++) {
+        read_frags(slot);                                             // X(t): read tile t (A multiplies tile t)
+        if (t + 1 < nk) wait_in_flight(t + 2 < nk ? 1 : 0);
+        phase_barrier();                                              // B1(t)
+        if (t + 3 < nk) stage(t + 3, slot);                           // Y(t): refill, multiply tile t
+        mfma_all();
+        phase_barrier();                                              // B2(t)
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------
@@ -322,11 +400,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2>
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false>
 static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int LDS = NS * (BM + BN) * 128;
-  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS>;
+  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -363,7 +441,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //  11  256x160   3      156 KiB   8 waves, 1 block/CU, two K-tiles of DMA in flight
 //  12  256x160   2      104 KiB   8 waves
 //  13  256x128   3      144 KiB   8 waves
-constexpr int N_GEMM_CFG = 16;
+constexpr int N_GEMM_CFG = 20;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 template <bool CONV>
@@ -385,6 +463,10 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 13: return launch_cfg<4, 2, 4, 4, CONV, 3>(ctx, k, batch);
     case 14: return launch_cfg<2, 2, 8, 5, CONV, 3>(ctx, k, batch);
     case 15: return launch_cfg<2, 2, 8, 5, CONV, 2>(ctx, k, batch);
+    case 16: return launch_cfg<4, 2, 4, 5, CONV, 3, true>(ctx, k, batch);  // 256x160 ping-pong
+    case 17: return launch_cfg<4, 2, 2, 5, CONV, 3, true>(ctx, k, batch);  // 128x160 ping-pong
+    case 18: return launch_cfg<4, 2, 4, 4, CONV, 3, true>(ctx, k, batch);  // 256x128 ping-pong
+    case 19: return launch_cfg<4, 2, 2, 4, CONV, 3, true>(ctx, k, batch);  // 128x128 ping-pong
     default: TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
   }
 }
@@ -447,6 +529,54 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   *ms = t / iters;
   ctx->arena.top = 0;
   return r;
+}
+
+// Debug entry: run one problem with tile configuration `cfg` and with the reference configuration `ref_cfg`, compare
+// the two outputs on the host (the 2-stage configurations are validated against the oracle by the test-suite).
+extern "C" int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups,
+                                    int cfg, int ref_cfg, float* max_abs_diff, float* max_abs_ref) {
+  if (!ctx || !max_abs_diff || !max_abs_ref) TSD_FAIL(TSD_E_ARG, "gemm_check: bad argument");
+  if (cfg >= N_GEMM_CFG || ref_cfg >= N_GEMM_CFG) TSD_FAIL(TSD_E_ARG, "gemm_check: cfg out of range");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int Hi = ups ? 2 * H : H, Wi = ups ? 2 * W : W;
+  const int Ho = conv ? (Hi + 2 - 3) / stride + 1 : H, Wo = conv ? (Wi + 2 - 3) / stride + 1 : W;
+  const int64_t M = (int64_t)B * Ho * Wo, K = conv ? 9 * (int64_t)Cin : Cin;
+  const int64_t na = (int64_t)B * H * W * Cin, nw = (int64_t)N * K, nc = M * N;
+  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + 2 * nc) * 2 + (size_t)std::max(na, nw) * 4 + 8192));
+  ctx->arena.top = 0;
+  half_t* A = arena_alloc<half_t>(ctx, na);
+  half_t* Wt = arena_alloc<half_t>(ctx, nw);
+  half_t* C0 = arena_alloc<half_t>(ctx, nc);
+  half_t* C1 = arena_alloc<half_t>(ctx, nc);
+  float* tmp = arena_alloc<float>(ctx, std::max(na, nw));
+  if (!A || !Wt || !C0 || !C1 || !tmp) TSD_FAIL(TSD_E_ALLOC, "gemm_check: arena");
+  TSD_TRY(launch_fill_uniform(ctx, tmp, na, 1, 1, 1.f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)na, A, (int)na, 1));
+  TSD_TRY(launch_fill_uniform(ctx, tmp, nw, 1, 2, 0.05f));
+  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nw, Wt, (int)nw, 1));
+  GemmArgs g;
+  g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.ldc = N;
+  if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
+  g.C = C0; g_force_cfg = ref_cfg;
+  int r = launch_gemm(ctx, g);
+  g.C = C1; g_force_cfg = cfg;
+  if (r == TSD_OK) r = launch_gemm(ctx, g);
+  g_force_cfg = -1;
+  if (r != TSD_OK) return r;
+  std::vector<half_t> h0(nc), h1(nc);
+  HIP_TRY(hipMemcpyAsync(h0.data(), C0, nc * 2, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(h1.data(), C1, nc * 2, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  float md = 0.f, mr = 0.f;
+  for (int64_t i = 0; i < nc; i++) {
+    const float a0 = (float)h0[i], a1 = (float)h1[i];
+    const float d = fabsf(a0 - a1);
+    if (!(d <= md)) md = d;  // NaN propagates
+    if (fabsf(a0) > mr) mr = fabsf(a0);
+  }
+  *max_abs_diff = md; *max_abs_ref = mr;
+  ctx->arena.top = 0;
+  return TSD_OK;
 }
 
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {

@@ -91,6 +91,7 @@ def _declare(l):
         "tsd_flop_count": ([i, i, i], C.c_double),
         "tsd_debug_gemm_bench": ([vp, i, i, i, i, i, i, i, i, i, i, fp], i),
         "tsd_debug_attn_bench": ([vp, i, i, i, i, i, i, fp], i),
+        "tsd_debug_gemm_check": ([vp, i, i, i, i, i, i, i, i, i, i, fp, fp], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(l, name)
