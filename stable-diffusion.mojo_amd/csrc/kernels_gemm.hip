@@ -23,6 +23,10 @@
 
 #include "common.h"
 
+#ifndef TSD_GEMM_PIN
+#define TSD_GEMM_PIN 1
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -40,9 +44,17 @@ struct GemmK {
   float out_scale;
 };
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// LDS-DMA through a buffer descriptor: 16 B per lane from (descriptor base + soff + voff) straight into LDS at
+// (wave-uniform l) + lane*16.  Lanes whose offset fails the descriptor's range check write ZEROS (verified by
+// scripts/micro/buflds_oob.hip, which also shows soff takes part in the check) - conv zero padding rides on that:
+// out-of-image taps carry the offset PAD_OFF, beyond the 2 GiB window every descriptor here spans.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned PAD_OFF = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, unsigned soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -93,12 +105,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   const int lrow = lane >> 3;
   const int cch = (lane & 7) ^ lrow;  // logical 16-B chunk this lane fetches (source-side swizzle)
 
-  // ---- per-thread source pointers -------------------------------------------------------
-  // 32-bit element offsets from the (wave-uniform) operand bases keep the loop's address state in
-  // one VGPR per row instead of a 64-bit pointer (all tensors on the path are < 2^32 elements).
-  unsigned a_off[A_PW];   // dense: row offset (same row index in both concat sources use their own pitch)
-  unsigned a_off1[A_PW];  // dense: row offset in the second source ; conv: current tap offset (~0u = zero tap)
-  int a_b[A_PW], a_iy[A_PW], a_ix[A_PW];
+  // ---- per-thread source offsets ---------------------------------------------------------
+  // 32-bit BYTE offsets from the (wave-uniform) descriptor bases; the K position goes in the scalar offset, so a
+  // DMA instruction costs no address VALU at all (every operand slice on the path is < 2 GiB, checked by the host).
+  unsigned a_off[A_PW];   // dense: row offset in the first source
+  unsigned a_off1[A_PW];  // dense: row offset in the second concat source ; conv: current tap offset (PAD_OFF = zero tap)
+  unsigned a_pk[A_PW];    // conv: (oy*stride-pad+1) | (ox*stride-pad+1) << 11 | b << 22   (b = 1023: row beyond M)
 #pragma unroll
   for (int i = 0; i < A_PW; i++) {
     const int row = (wave + i * NW) * 8 + lrow;
@@ -106,18 +118,16 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     const bool ok = m < p.M;
     if (!ok) m = p.M - 1;
     if constexpr (!CONV) {
-      a_off[i] = (unsigned)m * (unsigned)p.lda0 + cch * 8;
-      a_off1[i] = (unsigned)m * (unsigned)p.lda1 + cch * 8;
-      a_b[i] = a_iy[i] = a_ix[i] = 0;
+      a_off[i] = ((unsigned)m * (unsigned)p.lda0 + cch * 8) * 2;
+      a_off1[i] = ((unsigned)m * (unsigned)p.lda1 + cch * 8) * 2;
+      a_pk[i] = 0;
     } else {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_b[i] = ok ? b : -1;
-      a_iy[i] = oy * p.stride - p.pad;
-      a_ix[i] = ox * p.stride - p.pad;
+      a_pk[i] = (unsigned)(oy * p.stride - p.pad + 1) | (unsigned)(ox * p.stride - p.pad + 1) << 11 | (ok ? (unsigned)b : 1023u) << 22;
       a_off[i] = 0;
-      a_off1[i] = ~0u;
+      a_off1[i] = PAD_OFF;
     }
   }
   unsigned w_off[W_PW];
@@ -127,9 +137,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     const int wq = rho / BNw, rr = rho - wq * BNw, fn = rr >> 4, ii = rr & 15;
     int n = n0 + wq * BNw + (ii >> 2) * (4 * FN) + fn * 4 + (ii & 3);  // column permutation
     if (n >= p.N) n = p.N - 1;
-    w_off[i] = (unsigned)n * (unsigned)p.ldw + cch * 8;
+    w_off[i] = ((unsigned)n * (unsigned)p.ldw + cch * 8) * 2;
   }
-  const half_t* zsrc = p.zeros + cch * 8;
 
   // conv: running (tap, channel-chunk) of the NEXT tile to stage
   const int cpt = CONV ? (p.Cin >> 6) : 1;
@@ -139,56 +148,66 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     const int Heff = p.ups ? 2 * p.Hs : p.Hs, Weff = p.ups ? 2 * p.Ws : p.Ws;
 #pragma unroll
     for (int i = 0; i < A_PW; i++) {
-      const int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
-      const bool ok = a_b[i] >= 0 && (unsigned)iy < (unsigned)Heff && (unsigned)ix < (unsigned)Weff;
+      const int iy = (int)(a_pk[i] & 2047u) - 1 + kh, ix = (int)((a_pk[i] >> 11) & 2047u) - 1 + kw;
+      const unsigned b = a_pk[i] >> 22;
+      const bool ok = b != 1023u && (unsigned)iy < (unsigned)Heff && (unsigned)ix < (unsigned)Weff;
       const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
-      a_off1[i] = ok ? (unsigned)((a_b[i] * p.Hs + sy) * p.Ws + sx) * (unsigned)p.lda0 + cch * 8 : ~0u;
+      a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + sy) * p.Ws + sx) * (unsigned)p.lda0 + cch * 8) * 2 : PAD_OFF;
     }
   };
   if constexpr (CONV) conv_tap_ptrs(0);
 
-  auto stage = [&](int kt, int buf) {
+  // One K-tile = A_PW + W_PW DMA instructions per wave.  A TileSrc holds the wave-uniform part of their addresses;
+  // stage_piece() issues the i-th instruction so the pinned schedule can drop them one at a time into the shadow of
+  // the MFMAs; stage_advance() steps the conv (tap, chunk) cursor.  `live` = false builds descriptors with zero
+  // records: every lane is out of range and the DMA writes zeros, which lets the loop tail keep the same
+  // straight-line body instead of branching around the DMA.
+  struct TileSrc { rsrc_t ra, rw; unsigned a_soff, w_soff; bool second; };
+  auto tile_src = [&](int kt, bool live) {
+    TileSrc t;
+    const int nrec = live ? 0x7ffffff0 : 0;
+    const int k0 = kt * 64;
+    t.second = !CONV && k0 >= p.K0;  // wave-uniform: second concat source
+    if constexpr (CONV) {
+      t.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(A0), 0, nrec, 0x00020000);
+      t.a_soff = st_cc * 128;
+    } else {
+      t.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(t.second ? A1 : A0), 0, nrec, 0x00020000);
+      t.a_soff = (t.second ? k0 - p.K0 : k0) * 2;
+    }
+    t.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Wt), 0, nrec, 0x00020000);
+    t.w_soff = k0 * 2;
+    return t;
+  };
+  auto stage_piece = [&](const TileSrc& t, int buf, int i) {
     char* sA = smem + buf * TILE_BYTES;
     char* sW = sA + BM * 128;
-    const int k0 = kt * 64;
-    if constexpr (!CONV) {
-      if (k0 >= p.K0) {  // wave-uniform: second concat source
-        const half_t* base = A1 + (k0 - p.K0);
-#pragma unroll
-        for (int i = 0; i < A_PW; i++) {
-          const int j = wave + i * NW;
-          if (A_INSTR % NW == 0 || j < A_INSTR) glds16(base + a_off1[i], sA + j * 1024);
-        }
-      } else {
-        const half_t* base = A0 + k0;
-#pragma unroll
-        for (int i = 0; i < A_PW; i++) {
-          const int j = wave + i * NW;
-          if (A_INSTR % NW == 0 || j < A_INSTR) glds16(base + a_off[i], sA + j * 1024);
-        }
+    if (i < A_PW) {
+      const int j = wave + i * NW;
+      if (A_INSTR % NW == 0 || j < A_INSTR) {
+        if constexpr (!CONV) blds16(t.ra, t.second ? a_off1[i] : a_off[i], t.a_soff, sA + j * 1024);
+        else blds16(t.ra, a_off1[i], t.a_soff, sA + j * 1024);
       }
     } else {
-      const half_t* base = A0 + st_cc * 64;
-#pragma unroll
-      for (int i = 0; i < A_PW; i++) {
-        const int j = wave + i * NW;
-        if (A_INSTR % NW == 0 || j < A_INSTR) {
-          const half_t* src = (a_off1[i] != ~0u) ? base + a_off1[i] : zsrc;
-          glds16(src, sA + j * 1024);
-        }
-      }
+      const int iw = i - A_PW;
+      const int j = wave + iw * NW;
+      if (W_INSTR % NW == 0 || j < W_INSTR) blds16(t.rw, w_off[iw], t.w_soff, sW + j * 1024);
+    }
+  };
+  auto stage_advance = [&]() {
+    if constexpr (CONV) {
       if (++st_cc == cpt) {
         st_cc = 0;
         ++st_tap;
         if (st_tap < 9) conv_tap_ptrs(st_tap);
       }
     }
-    const half_t* wbase = Wt + k0;
+  };
+  auto stage = [&](int kt, int buf) {
+    const TileSrc t = tile_src(kt, true);
 #pragma unroll
-    for (int i = 0; i < W_PW; i++) {
-      const int j = wave + i * NW;
-      if (W_INSTR % NW == 0 || j < W_INSTR) glds16(wbase + w_off[i], sW + j * 1024);
-    }
+    for (int i = 0; i < A_PW + W_PW; i++) stage_piece(t, buf, i);
+    stage_advance();
   };
 
   f4 acc[FM][FN];
@@ -220,6 +239,35 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     }
   };
 
+  // whole-K-tile fragment set in registers (pinned-order and ping-pong schedules)
+  constexpr bool PIN = !PP && NS == 2 && (FM * FN * 4 + 8 * (FM + FN) + 56 <= 256) && (TSD_GEMM_PIN != 0);
+  h8 af[2][(PIN || PP) ? FM : 1], wf[2][(PIN || PP) ? FN : 1];
+  auto read_frags = [&](int buf) {
+    if constexpr (PIN || PP) {
+      const char* sA = smem + buf * TILE_BYTES;
+      const char* sW = sA + BM * 128;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        const int coff = ((kk * 4 + cq) ^ key) << 4;
+#pragma unroll
+        for (int b = 0; b < FN; b++) wf[kk][b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
+#pragma unroll
+        for (int a = 0; a < FM; a++) af[kk][a] = *(const h8*)(sA + a_rd + a * 2048 + coff);
+      }
+    }
+  };
+  auto mfma_all = [&]() {
+    if constexpr (PIN || PP) {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int a = 0; a < FM; a++)
+#pragma unroll
+          for (int b = 0; b < FN; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
+    }
+  };
+
   const int nk = p.K >> 6;
   // DMA instructions per stage per wave: waves below the remainder issue one more (wave-uniform)
   constexpr int LPS_HI = A_PW + W_PW;
@@ -239,36 +287,38 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
       asm volatile("" ::: "memory");
-      if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
-      compute(cur);
+      if constexpr (PIN) {
+        // Pinned issue order: all 2*(FM+FN) fragment reads first, then the MFMAs in fragment-arrival order behind the
+        // compiler's counted lgkmcnt waits, with the next tile's DMA instructions dropped one at a time into the
+        // MFMA shadow.  hipcc's own schedule front-loads the DMA address math and sinks some reads between MFMA
+        // groups behind lgkmcnt(0), exposing 3-4 LDS round trips per K-tile.
+        read_frags(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        const TileSrc t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
+        constexpr int NP = A_PW + W_PW, NM = 2 * FM * FN, GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+          const int kk = q / (FM * FN), a = (q / FN) % FM, b = q % FN;
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
+          if ((q + 1) % GAP == 0 && (q + 1) / GAP - 1 < NP) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_piece(t, nxt, (q + 1) / GAP - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int i = NM / GAP; i < NP; i++) stage_piece(t, nxt, i);  // more DMA instructions than MFMA gaps (thin tiles)
+        stage_advance();
+      } else {
+        if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+        compute(cur);
+      }
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
   } else {
     static_assert(!PP || (NW == 8 && NS == 3), "ping-pong schedule: 8 waves, 3-slot ring");
     const bool grpB = wave >= 4;
-    h8 af[2][FM], wf[2][FN];
-    auto read_frags = [&](int buf) {
-      const char* sA = smem + buf * TILE_BYTES;
-      const char* sW = sA + BM * 128;
-#pragma unroll
-      for (int kk = 0; kk < 2; kk++) {
-        const int coff = ((kk * 4 + cq) ^ key) << 4;
-#pragma unroll
-        for (int a = 0; a < FM; a++) af[kk][a] = *(const h8*)(sA + a_rd + a * 2048 + coff);
-#pragma unroll
-        for (int b = 0; b < FN; b++) wf[kk][b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
-      }
-    };
-    auto mfma_all = [&]() {
-#pragma unroll
-      for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-        for (int a = 0; a < FM; a++)
-#pragma unroll
-          for (int b = 0; b < FN; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
-    };
     // wait until at most `n` of this wave's most recent K-tiles are still in flight
     auto wait_in_flight = [&](int n) {
       if (n >= 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
@@ -589,6 +639,14 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     if (a.batch != 1) TSD_FAIL(TSD_E_ARG, "conv3x3: batch is folded into M");
   } else {
     if (a.K0 % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: concat split K0=%d must be a multiple of 64", a.K0);
+  }
+  {  // the kernel addresses each operand slice through a 2 GiB buffer-descriptor window with 32-bit byte offsets
+    const long long lim = 0x7ffffff0LL - 65536;
+    const long long a_bytes = a.conv ? 2LL * (a.M / (a.Ho * a.Wo)) * a.Hs * a.Ws * a.lda0
+                                     : 2LL * ((long long)(a.M - 1) * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) + a.K);
+    const long long w_bytes = 2LL * ((long long)(a.N - 1) * a.ldw + a.K);
+    if (a_bytes > lim || w_bytes > lim)
+      TSD_FAIL(TSD_E_SHAPE, "gemm: operand slice of %lld / %lld bytes exceeds the 2 GiB addressing window", a_bytes, w_bytes);
   }
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, a.conv ? KC_CONV : KC_GEMM, a.M, a.N, a.K, a.batch);
