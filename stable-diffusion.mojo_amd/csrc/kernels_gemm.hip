@@ -26,6 +26,9 @@
 #ifndef TSD_GEMM_PIN
 #define TSD_GEMM_PIN 1
 #endif
+#ifndef TSD_GEMM_PIN_MAXNS
+#define TSD_GEMM_PIN_MAXNS 4
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   };
 
   // whole-K-tile fragment set in registers (pinned-order and ping-pong schedules)
-  constexpr bool PIN = !PP && NS == 2 && (FM * FN * 4 + 8 * (FM + FN) + 56 <= 256) && (TSD_GEMM_PIN != 0);
+  constexpr bool PIN = !PP && (NS <= TSD_GEMM_PIN_MAXNS) && (FM * FN * 4 + 8 * (FM + FN) + 56 <= 256) && (TSD_GEMM_PIN != 0);
   h8 af[2][(PIN || PP) ? FM : 1], wf[2][(PIN || PP) ? FN : 1];
   auto read_frags = [&](int buf) {
     if constexpr (PIN || PP) {
@@ -525,12 +528,13 @@ static int choose_cfg(int M, int N, int K, int batch) {
   if (N <= 16) return 4;
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
-  // measured on MI355X (scripts/bench_gemm.py): two 128-row blocks per CU win once there are >= 2 tiles per CU;
-  // below that 64-row tiles; with <= 1 tile per CU only a deep DMA ring keeps the MFMA pipe fed.
+  // measured on MI355X (scripts/bench_gemm.py, pinned issue order): two 128-row blocks per CU win once there are
+  // >= 2 tiles per CU; around one tile per CU a single 128-row block with a 3-slot DMA ring (one wave per SIMD, the
+  // pinned schedule keeps its MFMA pipe fed); below that 64-row tiles with 3 slots, 4 when K is long.
   const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
-  const long long t64 = (long long)ceil_div(M, 64) * ceil_div(N, BN) * batch;
   if (t128 >= 512) return n160 ? 0 : 2;
-  if (t64 >= 512) return n160 ? 1 : 3;
+  if (t128 >= 192) return n160 ? 5 : 8;
+  if (K >= 5760) return n160 ? 6 : 9;
   return n160 ? 7 : 10;
 }
 
