@@ -374,6 +374,104 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   const int g = lane >> 4;
   const int epi = p.epi;
   const int nb = n0 + wn * BNw + g * (4 * FN);
+
+  // Coalesced path (every tile shape but the thin N <= 16 one, N % 8 == 0).  The MFMA layout leaves each lane with
+  // 4*FN consecutive columns of one row, i.e. 8-byte pieces 8*FN bytes apart across the wave - store-issue bound
+  // when written directly.  Instead each wave transposes 32 rows at a time through its own slice of the (now idle)
+  // LDS ring in fp32, after the per-column terms, and then walks them row-major: every lane owns 8 consecutive
+  // columns, the residual arrives as one 16-B load, the result leaves as one 16-B store, and a wave instruction
+  // covers whole BNw*2-byte row segments.
+  if constexpr (FN >= 4 && FM % 2 == 0) {
+    if ((p.N & 7) == 0) {
+      constexpr int EPP = BNw + 4;               // LDS row pitch in floats (16-B aligned, breaks the power of two)
+      constexpr int CH = BNw / 8;                // 8-column chunks per row
+      constexpr int ITEMS = 32 * CH / 64;
+      static_assert((32 * CH) % 64 == 0, "chunks must divide evenly among the lanes");
+      static_assert(NW * 32 * EPP * 4 <= NS * TILE_BYTES, "epilogue staging must fit in the tile ring");
+      wait_vmcnt<0>();                 // every DMA (including the dead tail tiles) has landed ...
+      __builtin_amdgcn_s_barrier();    // ... and every wave is done reading the ring
+      asm volatile("" ::: "memory");
+      float* ep = (float*)smem + wave * (32 * EPP);
+#pragma unroll
+      for (int pass = 0; pass < FM / 2; pass++) {
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          const int a = pass * 2 + hf;
+          const int m = m0 + wm * BMw + a * 16 + rsel;
+          float v[4 * FN];
+#pragma unroll
+          for (int b = 0; b < FN; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[b * 4 + r] = acc[a][b][r] * p.out_scale;
+          if (epi & EPI_BIAS_M) {
+            const float bm = p.bias[m < p.M ? m : p.M - 1];
+#pragma unroll
+            for (int j = 0; j < 4 * FN; j++) v[j] += bm;
+          }
+          if (epi & EPI_BIAS_N) {
+#pragma unroll
+            for (int b = 0; b < FN; b++)
+              if (nb + b * 4 < p.N) {
+                const f4 bv = *(const f4*)(p.bias + nb + b * 4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+              }
+          }
+          if (epi & EPI_ROWVEC) {
+            const float* rv = p.rowvec + (long long)((m < p.M ? m : p.M - 1) / p.rows_per_batch) * p.rowvec_ld;
+#pragma unroll
+            for (int b = 0; b < FN; b++)
+              if (nb + b * 4 < p.N) {
+                const f4 bv = *(const f4*)(rv + nb + b * 4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+              }
+          }
+          float* row = ep + (hf * 16 + rsel) * EPP + g * (4 * FN);
+#pragma unroll
+          for (int b = 0; b < FN; b++) *(f4*)(row + b * 4) = f4{v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]};
+        }
+        // same-wave LDS operations complete in order: the row-major reads below see the stores above
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+          const int t = lane + 64 * i;
+          const int r = t / CH, c = t - r * CH;
+          const int m = m0 + wm * BMw + pass * 32 + r;
+          const int n = n0 + wn * BNw + c * 8;
+          const f4 x0 = *(const f4*)(ep + r * EPP + c * 8), x1 = *(const f4*)(ep + r * EPP + c * 8 + 4);
+          if (m >= p.M || n >= p.N) continue;
+          float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          if (epi & EPI_RESIDUAL) {
+            long long rrow = m;
+            if (epi & EPI_RES_UPS) {
+              const int hw = p.Ho * p.Wo;
+              const int bb = m / hw, rem = m - bb * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+              rrow = ((long long)bb * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+            }
+            const h8 rv = *(const h8*)(p.R + (long long)bz * p.sR + rrow * p.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += (float)rv[j];
+          }
+          if (epi & EPI_GEGLU) {
+            h4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (half_t)(v[2 * j] * gelu_tanh_f(v[2 * j + 1]));
+            *(h4*)((half_t*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + (n >> 1)) = o;
+          } else if (epi & EPI_OUT_F32) {
+            float* cp = (float*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + n;
+            *(f4*)cp = f4{v[0], v[1], v[2], v[3]};
+            *(f4*)(cp + 4) = f4{v[4], v[5], v[6], v[7]};
+          } else {
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (half_t)v[j];
+            *(h8*)((half_t*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + n) = o;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < FM; a++) {
     const int m = m0 + wm * BMw + a * 16 + rsel;
