@@ -32,6 +32,7 @@ print(f"{'shape':34s} " + " ".join(f"cfg{c:>2d}(TF)" for c in cfgs) + "   best  
 for conv, H, Cin, N, stride, ups, cnt, label in shapes:
     Ho = H // stride
     fl = 2.0 * B * Ho * Ho * N * Cin * (9 if conv else 1)
+    if os.environ.get("REAL_EPI"): os.environ["TSD_BENCH_EPI"] = "2" if "geglu1" in label else "1"
     res = []
     for c in cfgs:
         if N % 160 and c in (0, 1, 5, 6, 7):

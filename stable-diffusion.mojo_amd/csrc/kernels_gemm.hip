@@ -622,23 +622,30 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
   }
 }
 
-static int choose_cfg(int M, int N, int K, int batch) {
+static int choose_cfg(int M, int N, int K, int batch, bool conv) {
   if (N <= 16) return 4;
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
-  // measured on MI355X (scripts/bench_gemm.py, pinned issue order): two 128-row blocks per CU win once there are
-  // >= 2 tiles per CU; around one tile per CU a single 128-row block with a 3-slot DMA ring (one wave per SIMD, the
-  // pinned schedule keeps its MFMA pipe fed); below that 64-row tiles with 3 slots, 4 when K is long.
+  // measured on MI355X (scripts/bench_gemm.py with REAL_EPI=1, pinned issue order):
+  //  * >= 2 tiles of 128 rows per CU: two 4-wave blocks per CU (cfg 0/2);
+  //  * dense GEMMs whose 256x160 tiling is exactly one or two full rounds of the 256 CUs: the 8-wave tile (cfg 11)
+  //    halves the operand traffic per flop and its prologue/epilogue count;
+  //  * around one 128-row tile per CU: long K -> one 128-row block with a 3-slot DMA ring (one wave per SIMD, the
+  //    pinned schedule keeps its MFMA pipe fed), short K -> 64-row tiles, two blocks per CU (fixed costs overlap);
+  //  * fewer tiles than that: 64-row tiles with 3 ring slots, 4 when K is long.
   const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
+  const long long t256 = (long long)ceil_div(M, 256) * ceil_div(N, BN) * batch;
+  static const int tune = getenv("TSD_GEMM_TUNE") ? atoi(getenv("TSD_GEMM_TUNE")) : 3;  // A/B switch for the two rules below
+  if ((tune & 1) && !conv && n160 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
   if (t128 >= 512) return n160 ? 0 : 2;
-  if (t128 >= 192) return n160 ? 5 : 8;
+  if (t128 >= 192) return (K >= 2560 || !(tune & 2)) ? (n160 ? 5 : 8) : (n160 ? 1 : 3);
   if (K >= 5760) return n160 ? 6 : 9;
   return n160 ? 7 : 10;
 }
 
 template <bool CONV>
 static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
-  const int id = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(k.M, k.N, k.K, batch);
+  const int id = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV);
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
 
@@ -653,7 +660,7 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   const int Ho = conv ? (Hi + 2 - 3) / stride + 1 : H, Wo = conv ? (Wi + 2 - 3) / stride + 1 : W;
   const int64_t M = (int64_t)B * Ho * Wo, K = conv ? 9 * (int64_t)Cin : Cin;
   const int64_t na = (int64_t)B * H * W * Cin, nw = (int64_t)N * K, nc = M * N;
-  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + nc) * 2 + (size_t)std::max(na, nw) * 4 + 4096));
+  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + 2 * nc) * 2 + (size_t)std::max(na, nw) * 4 + (size_t)N * 4 + 8192));
   ctx->arena.top = 0;
   half_t* A = arena_alloc<half_t>(ctx, na);
   half_t* Wt = arena_alloc<half_t>(ctx, nw);
@@ -667,6 +674,17 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   GemmArgs g;
   g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.C = C; g.ldc = N;
   if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
+  // TSD_BENCH_EPI: 0 plain store, 1 bias + residual (projection / conv2 epilogue), 2 bias + GEGLU
+  const int epi_mode = getenv("TSD_BENCH_EPI") ? atoi(getenv("TSD_BENCH_EPI")) : 0;
+  if (epi_mode) {
+    float* bias = arena_alloc<float>(ctx, N);
+    half_t* R = arena_alloc<half_t>(ctx, epi_mode == 1 ? nc : 0);
+    if (!bias || (epi_mode == 1 && !R)) TSD_FAIL(TSD_E_ALLOC, "gemm_bench: arena");
+    TSD_TRY(launch_fill_uniform(ctx, bias, N, 1, 3, 0.1f));
+    g.bias = bias; g.epi = EPI_BIAS_N;
+    if (epi_mode == 1) { HIP_TRY(hipMemsetAsync(R, 0, (size_t)nc * 2, ctx->stream)); g.R = R; g.ldr = N; g.epi |= EPI_RESIDUAL; }
+    else { g.epi |= EPI_GEGLU; g.ldc = N / 2; }
+  }
   g_force_cfg = cfg;
   int r = launch_gemm(ctx, g);
   if (r == TSD_OK) r = launch_gemm(ctx, g);
