@@ -21,6 +21,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 #ifndef TSD_GEMM_PIN
@@ -45,6 +48,9 @@ struct GemmK {
   int Hs, Ws, Ho, Wo, Cin, stride, pad, ups;
   int epi, tiles_n;
   float out_scale;
+#ifdef TSD_GEMM_TS
+  unsigned long long* ts;  // per-block phase timestamps (experiment build only)
+#endif
 };
 
 // LDS-DMA through a buffer descriptor: 16 B per lane from (descriptor base + soff + voff) straight into LDS at
@@ -68,6 +74,13 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.f + t);
 }
 
+#ifdef TSD_GEMM_TS
+static unsigned long long* g_ts = nullptr;
+#define TS_MARK(i) do { if (p.ts && threadIdx.x == 0) p.ts[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS_MARK(i) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -88,6 +101,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   constexpr int TILE_BYTES = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  TS_MARK(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     for (int s = 0; s < NS - 1; s++)
       if (s < nk) stage(s, s);
     int cur = 0, nxt = NS - 1;  // ring slots of tile kt and tile kt+NS-1
+    TS_MARK(1);
     for (int kt = 0; kt < nk; kt++) {
       // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
       const int ahead = min(NS - 2, nk - 1 - kt);
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     }
   }
 
+  TS_MARK(2);
   // ---- epilogue ---------------------------------------------------------------------------
   const int g = lane >> 4;
   const int epi = p.epi;
@@ -388,9 +404,37 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       constexpr int ITEMS = 32 * CH / 64;
       static_assert((32 * CH) % 64 == 0, "chunks must divide evenly among the lanes");
       static_assert(NW * 32 * EPP * 4 <= NS * TILE_BYTES, "epilogue staging must fit in the tile ring");
-      wait_vmcnt<0>();                 // every DMA (including the dead tail tiles) has landed ...
+      // The residual tile is fetched NOW, in the row-major item layout, so its HBM/L2 round trip overlaps the DMA
+      // drain, the barrier and the LDS transposes instead of stalling every pass (measured with -DTSD_GEMM_TS: the
+      // residual cost 6 us of a 21 us 32768x320x320 GEMM when loaded inside the item loop).  Loads are unconditional
+      // (clamped addresses) so exactly RES_LOADS VMEM instructions are younger than the last DMA.
+      constexpr int RES_LOADS = (FM / 2) * ITEMS;
+      h8 resv[FM / 2][ITEMS];
+      if (epi & EPI_RESIDUAL) {
+        const half_t* rbase = p.R + (long long)bz * p.sR;
+#pragma unroll
+        for (int pass = 0; pass < FM / 2; pass++)
+#pragma unroll
+          for (int i = 0; i < ITEMS; i++) {
+            const int t = lane + 64 * i;
+            const int r = t / CH, c = t - r * CH;
+            const int m = min(m0 + wm * BMw + pass * 32 + r, p.M - 1);
+            const int n = min(n0 + wn * BNw + c * 8, p.N - 8);
+            long long rrow = m;
+            if (epi & EPI_RES_UPS) {
+              const int hw = p.Ho * p.Wo;
+              const int bb = m / hw, rem = m - bb * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+              rrow = ((long long)bb * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+            }
+            resv[pass][i] = *(const h8*)(rbase + rrow * p.ldr + n);
+          }
+        wait_vmcnt<RES_LOADS>();       // every DMA (including the dead tail tiles) has landed ...
+      } else {
+        wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();    // ... and every wave is done reading the ring
       asm volatile("" ::: "memory");
+      TS_MARK(3);
       float* ep = (float*)smem + wave * (32 * EPP);
 #pragma unroll
       for (int pass = 0; pass < FM / 2; pass++) {
@@ -442,13 +486,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
           if (m >= p.M || n >= p.N) continue;
           float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
           if (epi & EPI_RESIDUAL) {
-            long long rrow = m;
-            if (epi & EPI_RES_UPS) {
-              const int hw = p.Ho * p.Wo;
-              const int bb = m / hw, rem = m - bb * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-              rrow = ((long long)bb * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-            }
-            const h8 rv = *(const h8*)(p.R + (long long)bz * p.sR + rrow * p.ldr + n);
+            const h8 rv = resv[pass][i];
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] += (float)rv[j];
           }
@@ -469,6 +507,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
           }
         }
       }
+#ifdef TSD_GEMM_TS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TS_MARK(4);
+#endif
       return;
     }
   }
@@ -568,6 +610,9 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
     }
   }
   GemmK kk = k;
+#ifdef TSD_GEMM_TS
+  kk.ts = g_ts;
+#endif
   kk.tiles_n = ceil_div(k.N, BN);
   const int tiles_m = ceil_div(k.M, BM);
   dim3 grid(tiles_m * kk.tiles_n, batch);
@@ -610,14 +655,16 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 9: return launch_cfg<2, 2, 2, 4, CONV, 4>(ctx, k, batch);
     case 10: return launch_cfg<2, 2, 2, 4, CONV, 3>(ctx, k, batch);
     case 11: return launch_cfg<4, 2, 4, 5, CONV, 3>(ctx, k, batch);
-    case 12: return launch_cfg<4, 2, 4, 5, CONV, 2>(ctx, k, batch);
     case 13: return launch_cfg<4, 2, 4, 4, CONV, 3>(ctx, k, batch);
+#ifdef TSD_GEMM_EXPERIMENTAL  // measured, not faster: built only to reproduce those numbers
+    case 12: return launch_cfg<4, 2, 4, 5, CONV, 2>(ctx, k, batch);
     case 14: return launch_cfg<2, 2, 8, 5, CONV, 3>(ctx, k, batch);
     case 15: return launch_cfg<2, 2, 8, 5, CONV, 2>(ctx, k, batch);
     case 16: return launch_cfg<4, 2, 4, 5, CONV, 3, true>(ctx, k, batch);  // 256x160 ping-pong
     case 17: return launch_cfg<4, 2, 2, 5, CONV, 3, true>(ctx, k, batch);  // 128x160 ping-pong
     case 18: return launch_cfg<4, 2, 4, 4, CONV, 3, true>(ctx, k, batch);  // 256x128 ping-pong
     case 19: return launch_cfg<4, 2, 2, 4, CONV, 3, true>(ctx, k, batch);  // 128x128 ping-pong
+#endif
     default: TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
   }
 }
@@ -688,6 +735,31 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   g_force_cfg = cfg;
   int r = launch_gemm(ctx, g);
   if (r == TSD_OK) r = launch_gemm(ctx, g);
+#ifdef TSD_GEMM_TS
+  if (getenv("TSD_GEMM_TS")) {
+    const int nblk = 1 << 16;
+    unsigned long long* dts = nullptr;
+    HIP_TRY(hipMalloc((void**)&dts, (size_t)nblk * 64));
+    HIP_TRY(hipMemset(dts, 0, (size_t)nblk * 64));
+    g_ts = dts;
+    r = launch_gemm(ctx, g);
+    g_ts = nullptr;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h((size_t)nblk * 8);
+    HIP_TRY(hipMemcpy(h.data(), dts, (size_t)nblk * 64, hipMemcpyDeviceToHost));
+    hipFree(dts);
+    unsigned long long tmin = ~0ull, tmax = 0; int n = 0;
+    for (int b = 0; b < nblk; b++) if (h[b * 8]) { n++; tmin = std::min(tmin, h[b * 8]); tmax = std::max(tmax, h[b * 8 + 4]); }
+    fprintf(stderr, "[ts] blocks=%d kernel span=%llu ticks\n", n, tmax - tmin);
+    const char* nm[5] = {"start-after-first-block", "prologue", "main loop", "drain+barrier", "epilogue"};
+    for (int ph = 0; ph < 5; ph++) {
+      std::vector<unsigned long long> d;
+      for (int b = 0; b < nblk; b++) if (h[b * 8]) d.push_back(ph == 0 ? h[b * 8] - tmin : h[b * 8 + ph] - h[b * 8 + ph - 1]);
+      std::sort(d.begin(), d.end());
+      fprintf(stderr, "[ts] %-24s min %8llu  med %8llu  p90 %8llu  max %8llu\n", nm[ph], d.front(), d[d.size() / 2], d[d.size() * 9 / 10], d.back());
+    }
+  }
+#endif
   if (r != TSD_OK) { g_force_cfg = -1; return r; }
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
   for (int i = 0; i < iters && r == TSD_OK; i++) r = launch_gemm(ctx, g);
