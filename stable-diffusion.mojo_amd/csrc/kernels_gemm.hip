@@ -46,7 +46,7 @@ struct GemmK {
   int lda0, lda1, K0, ldw, ldr, ldc, rowvec_ld, rows_per_batch;
   int M, N, K;
   int Hs, Ws, Ho, Wo, Cin, stride, pad, ups;
-  int epi, tiles_n;
+  int epi, tiles_n, xcd_n;
   float out_scale;
 #ifdef TSD_GEMM_TS
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
@@ -107,12 +107,25 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware bijective remap (block b runs on XCD b%8; give each XCD a contiguous tile range).
+  // The 8 XCDs form an (8/xcd_n) x xcd_n grid over the tile space: an XCD owns a contiguous block of tile rows AND of
+  // tile columns, so through its private L2 it pulls 1/xcd_n of W and xcd_n/8 of A.  The host picks xcd_n to minimise
+  // the fabric traffic W_bytes * (8/xcd_n) + A_bytes * xcd_n (weight-heavy M = 2048 problems want xcd_n = 8: with
+  // row-only ownership every XCD re-fetched the whole 29 MB conv weight).  xcd_n = 1 is the row-only bijective remap.
   int bid = blockIdx.x;
-  {
+  int tm, tn;
+  if (p.xcd_n > 1) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int xi = xcd / p.xcd_n, xj = xcd - xi * p.xcd_n;
+    const int tnx = p.tiles_n / p.xcd_n, tmx = (gridDim.x / p.tiles_n) / (8 / p.xcd_n);
+    const int ltm = idx / tnx, ltn = idx - ltm * tnx;
+    tm = xi * tmx + ltm;
+    tn = xj * tnx + ltn;
+  } else {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tm = bid / p.tiles_n;
+    tn = bid - tm * p.tiles_n;
   }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int bz = blockIdx.y;
   const half_t* A0 = p.A0 + (long long)bz * p.sA;
@@ -300,7 +313,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     for (int kt = 0; kt < nk; kt++) {
       // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
       const int ahead = min(NS - 2, nk - 1 - kt);
-      if (NS >= 4 && ahead >= 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
+      if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
+      else if (NS >= 5 && ahead == 3) { if (lps_hi) wait_vmcnt<3 * LPS_HI>(); else wait_vmcnt<3 * LPS_LO>(); }
+      else if (NS >= 4 && ahead == 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
       else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
@@ -615,6 +630,21 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 #endif
   kk.tiles_n = ceil_div(k.N, BN);
   const int tiles_m = ceil_div(k.M, BM);
+  {  // XCD grid: minimise W_bytes * xm + A_bytes * xn over the factorizations of 8 that divide the tile grid
+    static const int force = getenv("TSD_GEMM_XCDN") ? atoi(getenv("TSD_GEMM_XCDN")) : 0;
+    const double wb = 2.0 * k.N * k.K;
+    const double ab = CONV ? 2.0 * (k.M / (k.Ho * k.Wo)) * k.Hs * k.Ws * k.Cin : 2.0 * (double)k.M * k.K;
+    int best = 1;
+    double best_cost = wb * 8 + ab;
+    for (int xn = 2; xn <= 8; xn *= 2) {
+      const int xm = 8 / xn;
+      if (kk.tiles_n % xn || tiles_m % xm) continue;
+      const double cost = wb * xm + ab * xn;
+      if (cost < best_cost) { best_cost = cost; best = xn; }
+    }
+    if (force > 0) best = (kk.tiles_n % force == 0 && tiles_m % (8 / force) == 0) ? force : 1;
+    kk.xcd_n = best;
+  }
   dim3 grid(tiles_m * kk.tiles_n, batch);
   hipLaunchKernelGGL(fn, grid, dim3(WGM * WGN * 64), LDS, ctx->stream, kk);
   HIP_TRY(hipGetLastError());
@@ -637,7 +667,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //  11  256x160   3      156 KiB   8 waves, 1 block/CU, two K-tiles of DMA in flight
 //  12  256x160   2      104 KiB   8 waves
 //  13  256x128   3      144 KiB   8 waves
-constexpr int N_GEMM_CFG = 20;
+constexpr int N_GEMM_CFG = 22;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 template <bool CONV>
@@ -664,6 +694,8 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 17: return launch_cfg<4, 2, 2, 5, CONV, 3, true>(ctx, k, batch);  // 128x160 ping-pong
     case 18: return launch_cfg<4, 2, 4, 4, CONV, 3, true>(ctx, k, batch);  // 256x128 ping-pong
     case 19: return launch_cfg<4, 2, 2, 4, CONV, 3, true>(ctx, k, batch);  // 128x128 ping-pong
+    case 20: return launch_cfg<2, 2, 2, 5, CONV, 5>(ctx, k, batch);  // 64x160, 5-slot ring: slower than 4 slots (667 vs 821 TF)
+    case 21: return launch_cfg<2, 2, 2, 4, CONV, 6>(ctx, k, batch);  // 64x128, 6-slot ring
 #endif
     default: TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
   }
