@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=77)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the VAE-decode timing used for images/s")
+    ap.add_argument("--img2img", action="store_true",
+                    help="also time the VAE encoder and report BASELINE configs[3] (encoder + 30 steps + decoder) as an extra field")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,6 +216,17 @@ def main():
             dec_ms = ctx.timer_stop()
         ms_per_step = 1e3 * dt / K
         steps_per_s = world * K / dt
+        # ---- BASELINE configs[3] (img2img): VAE encoder on B x (3,512,512) + strength 0.6 of the schedule + decoder ----
+        enc_ms = None
+        if args.img2img and dec is not None:
+            enc = tsd.Encoder(seed=SEED, ctx=ctx)
+            img = tsd.rng.uniform(SEED, 7, B * 3 * 64 * L * L, 1.0).reshape(B, 3, 8 * L, 8 * L)
+            nz = tsd.rng.normal(SEED, 8, B * 4 * L * L).reshape(B, 4, L, L)
+            enc.forward(img, nz)
+            t0 = time.time()
+            enc.forward(img, nz)  # boundary call: host buffers in and out (PCIe-inclusive)
+            enc_ms = 1e3 * (time.time() - t0)
+            enc.model.close()
         images_per_s = (world * B) / ((n_sched * ms_per_step + (dec_ms or 0.0)) / 1e3)
         cpu = None
         if not args.no_cpu_baseline:
@@ -230,6 +243,9 @@ def main():
                                    f"{T}-token context, no CFG, random-init weights (BASELINE configs[1])",
                        "global_batch": world * B, "parallelism": f"dp{world} (independent prompts, weights broadcast once)"},
             "images_per_s_end_to_end": round(images_per_s, 4), "decode_ms": None if dec_ms is None else round(dec_ms, 3),
+            "img2img_config4": None if enc_ms is None else {
+                "encode_ms_host_boundary": round(enc_ms, 3), "steps": int(n_sched * 0.6),
+                "images_per_s": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
             "event_ms_per_step": round(ev_ms / K, 4), "output_finite": finite,
             "frac_of_fp16_mfma_peak_whole_step": round(whole_frac, 4),
             "weight_broadcast_s": round(bcast_s, 4), "weight_broadcast_bytes": bcast_bytes,

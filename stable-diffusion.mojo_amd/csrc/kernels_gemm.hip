@@ -794,7 +794,11 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
 #endif
   if (r != TSD_OK) { g_force_cfg = -1; return r; }
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-  for (int i = 0; i < iters && r == TSD_OK; i++) r = launch_gemm(ctx, g);
+  const int alt = getenv("TSD_BENCH_ALTCFG") ? atoi(getenv("TSD_BENCH_ALTCFG")) : -1;  // alternate two kernels (cold I-cache probe)
+  for (int i = 0; i < iters && r == TSD_OK; i++) {
+    if (alt >= 0) g_force_cfg = (i & 1) ? alt : cfg;
+    r = launch_gemm(ctx, g);
+  }
   g_force_cfg = -1;
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));

@@ -141,6 +141,36 @@ def test_generate_pipeline_runs(gpu_ctx, tsd_mod, diffusion, decoder):
     assert img.min() >= 0.0 and img.max() <= 255.0
 
 
+def test_img2img_matches_oracle(gpu_ctx, tsd_mod, diffusion, decoder, unet_params, dec_params):
+    """BASELINE config-4 shape of the path at 64 px: encoder -> add_noise at timesteps[start] -> the last
+    int(steps*strength) DDPM steps -> decoder -> rescale (pipeline.mojo:66-79, sampler.mojo:67-73,111-124)."""
+    B, L, steps, strength, seed = 1, 8, 5, 0.6, 21
+    nl = B * 4 * L * L
+    _, ctx = _inputs(B, L, tag=610)
+    image = rng.uniform(SEED, 612, 3 * 64 * 64, 1.0).reshape(1, 3, 64, 64) * 127.5 + 127.5  # [0,255]
+    enc = tsd_mod.Encoder(seed=SEED)
+    out = tsd_mod.generate(diffusion, decoder, ctx, cfg=False, inference_steps=steps, seed_val=seed, L=L,
+                           input_image=image, encoder=enc, strength=strength)
+    enc.model.close()
+    # the same pipeline on the oracle, with generate()'s RNG streams
+    P_enc = spec.init_params("encoder", SEED, only_used=True)
+    s = sampler.DDPMSampler(1000)
+    s.set_inference_timesteps(steps)
+    s.set_strength(strength)
+    n = len(s.timesteps)
+    assert n == 3
+    img = (image / 127.5 - 1.0).astype(np.float32)
+    lat = models.encoder(P_enc, img[0], rng.normal(seed, 1, nl).reshape(B, 4, L, L)[0])
+    lat = s.add_noise(lat, s.timesteps[0], rng.normal(seed, 4, nl).reshape(B, 4, L, L)[0])
+    noises = rng.normal(seed, 3, n * nl).reshape(n, B, 4, L, L)[:, 0]
+    x = sampler.denoise(unet_params, lat, ctx[0], steps, noises, timesteps=s.timesteps)
+    ref = ops.rescale_to_u8_range(models.decoder(dec_params, x))[None]
+    assert out.shape == ref.shape == (1, 3, 64, 64)
+    err = float(np.abs(out - ref).mean())
+    print(f"[parity] img2img 64px, 3 of 5 steps: mean |diff| = {err:.4f} of 255, rel_l2 = {rel_l2(out, ref):.3e}")
+    assert err < 0.5 and rel_l2(out, ref) < TOL_MODEL
+
+
 def test_per_struct_composition_equals_fused_module(gpu_ctx, tsd_mod, unet_params):
     """`UNet` composed from the per-struct calls (diffusion.mojo:228-273 literally, incl. concats and Upsample)
     == the fused device graph behind `Diffusion.forward` (dead-concat elimination, folded upsample)."""
