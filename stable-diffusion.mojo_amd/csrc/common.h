@@ -102,6 +102,10 @@ int ctx_reserve_staging(tsd_ctx* ctx, size_t bytes);
 struct Act {  // [B][H][W][C] with row pitch ld (elements) between pixels
   half_t* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0, ld = 0;
+  // GroupNorm statistics emitted by the producing GEMM/conv epilogue (EPI_GNSTATS): gn_buf/gn_groups are set by whoever
+  // allocates the tensor (capacity B * (H*W/32) * gn_groups * 2 floats); gn_part/gn_nslab by the producer if it could.
+  float* gn_buf = nullptr; int gn_groups = 0;
+  const float* gn_part = nullptr; int gn_nslab = 0;
   int64_t pixels() const { return (int64_t)B * H * W; }
 };
 
@@ -140,6 +144,8 @@ enum : int {
   EPI_RES_UPS = 16,  // residual is read through a nearest-2x upsample of a (Ho/2, Wo/2) tensor
   EPI_GEGLU = 32,    // out[m][n/2] = a * gelu_tanh(g) for interleaved (a,g) column pairs
   EPI_OUT_F32 = 64,  // store fp32 instead of fp16
+  EPI_GNSTATS = 128, // also emit per-(sample, row slab, group) sum / sum of squares of the rounded output: the statistics
+                     // pass of the GroupNorm that consumes this tensor (gn_* fields)
 };
 
 struct GemmArgs {
@@ -158,8 +164,11 @@ struct GemmArgs {
   const half_t* R = nullptr; int ldr = 0;
   void* C = nullptr; int ldc = 0;
   float out_scale = 1.f;  // applied to the accumulator before bias/residual
+  // EPI_GNSTATS: partial[(b * gn_nslab + slab) * gn_groups + g][2], slab = wave-tile row block within the sample
+  float* gn_part = nullptr; int gn_groups = 0, gn_rows_per_sample = 0, gn_nslab = 0;
 };
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a);
+int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups);  // 0: not available
 
 // ---- other kernel launchers -----------------------------------------------------------
 // layout / elementwise (kernels_elementwise.hip)
@@ -198,7 +207,7 @@ struct NormSrc {
   const half_t* x1 = nullptr; int ld1 = 0;
 };
 int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
-                     int silu, half_t* y, int ldy);
+                     int silu, half_t* y, int ldy, const float* pre_part = nullptr, int pre_nslab = 0);
 int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy);
 
 // attention (kernels_attn.hip): fused flash attention for d_head in {40, 80, 160}.

@@ -13,8 +13,28 @@ static int zero_async(tsd_ctx* ctx, void* p, size_t bytes) {
   return TSD_OK;
 }
 
+Act act_alloc_gn(tsd_ctx* ctx, int B, int H, int W, int C, int groups) {
+  Act a = act_alloc(ctx, B, H, W, C);
+  if (a.p && groups > 0 && C % groups == 0) {
+    a.gn_buf = arena_alloc<float>(ctx, (int64_t)B * ceil_div(H * W, 32) * groups * 2);
+    a.gn_groups = a.gn_buf ? groups : 0;
+  }
+  return a;
+}
+
+// ask the GEMM/conv that writes `dst` to emit the statistics of the GroupNorm that will read it (EPI_GNSTATS); a tile
+// geometry that cannot do it leaves dst->gn_part NULL and the consumer runs its own statistics pass.
+static void gn_emit(GemmArgs& g, Act* dst, int rows_per_sample) {
+  if (!dst || !dst->gn_buf || dst->gn_groups <= 0 || g.N != dst->C || (g.epi & (EPI_OUT_F32 | EPI_GEGLU))) return;
+  const int ns = gemm_gnstats_slabs(g.M, g.N, g.K, g.batch, g.conv, rows_per_sample, dst->gn_groups);
+  if (ns <= 0 || ns > ceil_div(rows_per_sample, 32) || ns > 128) return;  // every apply block re-reduces the slabs: keep them few
+  g.epi |= EPI_GNSTATS;
+  g.gn_part = dst->gn_buf; g.gn_groups = dst->gn_groups; g.gn_rows_per_sample = rows_per_sample; g.gn_nslab = ns;
+  dst->gn_part = dst->gn_buf; dst->gn_nslab = ns;
+}
+
 int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, int pad_br, int ups,
-              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy) {
+              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy, Act* stat) {
   if (w.k != 3) TSD_FAIL(TSD_E_SHAPE, "g_conv3x3: kernel size %d", w.k);
   if (x.ld < w.Ipad) TSD_FAIL(TSD_E_SHAPE, "g_conv3x3: input pitch %d < padded Cin %d", x.ld, w.Ipad);
   const int Hin = ups ? 2 * x.H : x.H, Win = ups ? 2 * x.W : x.W;
@@ -32,11 +52,12 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
   if (res) { g.epi |= EPI_RESIDUAL | (res_ups ? EPI_RES_UPS : 0); g.R = res->p; g.ldr = res->ld; }
   if (out_f32) g.epi |= EPI_OUT_F32;
   g.C = y; g.ldc = ldy;
+  gn_emit(g, stat, Ho * Wo);
   return launch_gemm(ctx, g);
 }
 
 int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
-             const half_t* res, int ldr, int epi_extra, void* y, int ldy) {
+             const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat, int rows_per_sample) {
   GemmArgs g;
   g.A0 = a.p0; g.lda0 = a.ld0;
   if (a.p1 && K > a.C0) { g.A1 = a.p1; g.lda1 = a.ld1; g.K0 = a.C0; }
@@ -45,6 +66,7 @@ int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw,
   if (bias) { g.epi |= EPI_BIAS_N; g.bias = bias; }
   if (res) { g.epi |= EPI_RESIDUAL; g.R = res; g.ldr = ldr; }
   g.C = y; g.ldc = ldy;
+  gn_emit(g, stat, rows_per_sample);
   return launch_gemm(ctx, g);
 }
 
@@ -57,7 +79,7 @@ static NormSrc norm_src(const CatSrc& x, int C) {
 
 // `Unet_Residual_Block.forward` diffusion.mojo:54-72 / VAE `Res_Block.forward` vae.mojo:57-67
 int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
-               int tld, Act out) {
+               int tld, Act& out) {
   const int cin = w.cin, cout = w.cout;
   if (cin % 64 || cout % 64) TSD_FAIL(TSD_E_SHAPE, "residual block: channels (%d,%d) must be multiples of 64", cin, cout);
   if (cin > x.C0 + (x.p1 ? x.C1 : 0)) TSD_FAIL(TSD_E_SHAPE, "residual block: input has fewer than %d channels", cin);
@@ -67,11 +89,14 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   const size_t mark = ctx->arena.mark();
   // GN -> SiLU (only the first cin channels are normalised/consumed: App.A D11)
   Act h = act_alloc(ctx, B, Hin, Win, cin); CHECK_ALLOC(h.p);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, 1e-5f, 1.f, 1, h.p, h.ld));
-  Act t1 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(t1.p);
-  TSD_TRY(g_conv3x3(ctx, h, w.conv1, 1, 1, 1, ups, tvec ? tvec + w.time_off : nullptr, tld, nullptr, 0, false, t1.p, t1.ld));
+  const bool x_stats = !(x.p1 && cin > x.C0) && x.gn_part0 && x.gn_groups0 == w.groups && x.C0 == cin;
+  TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, 1e-5f, 1.f, 1, h.p, h.ld,
+                           x_stats ? x.gn_part0 : nullptr, x.gn_nslab0));
+  Act t1 = act_alloc_gn(ctx, B, H, W, cout, w.groups); CHECK_ALLOC(t1.p);
+  TSD_TRY(g_conv3x3(ctx, h, w.conv1, 1, 1, 1, ups, tvec ? tvec + w.time_off : nullptr, tld, nullptr, 0, false, t1.p, t1.ld, &t1));
   Act h3 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(h3.p);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, 1e-5f, 1.f, 1, h3.p, h3.ld));
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, 1e-5f, 1.f, 1, h3.p, h3.ld, t1.gn_part,
+                           t1.gn_nslab));
   Act r;
   if (w.has_skip) {  // 1x1 conv on the raw input, at the INPUT resolution (commutes with nearest upsample)
     r = act_alloc(ctx, B, Hin, Win, cout); CHECK_ALLOC(r.p);
@@ -80,13 +105,13 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   } else {
     r.p = const_cast<half_t*>(x.p0); r.ld = x.ld0; r.B = B; r.H = Hin; r.W = Win; r.C = cout;
   }
-  TSD_TRY(g_conv3x3(ctx, h3, w.conv2, 1, 1, 1, 0, nullptr, 0, &r, ups, false, out.p, out.ld));
+  TSD_TRY(g_conv3x3(ctx, h3, w.conv2, 1, 1, 1, 0, nullptr, 0, &r, ups, false, out.p, out.ld, &out));
   ctx->arena.release(mark);
   return TSD_OK;
 }
 
 // `Unet_Attention_Block.forward` diffusion.mojo:112-147 on NHWC tokens
-int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out,
+int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act& out,
                 const CtxKV* pre) {
   const int C = w.C, B = x.B, S = x.H * x.W, d = w.n_embed, Hh = w.n_head;
   const int64_t M = (int64_t)B * S;
@@ -96,7 +121,9 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   const size_t mark = ctx->arena.mark();
   const float scale = 1.f / sqrtf((float)d);  // helpers/attention.mojo:57-58
   half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C));  // :89,:116
+  const bool x_stats = x.gn_part && x.gn_groups == 32;
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr,
+                           x.gn_nslab));  // :89,:116
   half_t* tok = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok);
   CatSrc a; a.p0 = h0; a.ld0 = C; a.C0 = C;
   TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C));  // :117
@@ -170,7 +197,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C));
   // ---- output 1x1 conv + long residual (:146) ----
   a.p0 = tok4;
-  TSD_TRY(g_linear(ctx, a, M, w.conv_out.w, w.conv_out.Ipad, C, C, w.conv_out.b, x.p, x.ld, 0, out.p, out.ld));
+  TSD_TRY(g_linear(ctx, a, M, w.conv_out.w, w.conv_out.Ipad, C, C, w.conv_out.b, x.p, x.ld, 0, out.p, out.ld, &out, S));
   ctx->arena.release(mark);
   return TSD_OK;
 }
@@ -224,13 +251,14 @@ int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& i
 }
 
 // VAE `Attention_Block.forward` vae.mojo:17-27: GroupNorm(32) -> one head of width C -> + x
-int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act out) {
+int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act& out) {
   const int C = w.C, B = x.B, S = x.H * x.W;
   const int64_t M = (int64_t)B * S;
   if (C % 64 || S % 8) TSD_FAIL(TSD_E_SHAPE, "vae attention: C=%d, H*W=%d unsupported", C, S);
   const size_t mark = ctx->arena.mark();
   half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-5f, 1.f, 0, h0, C));
+  const bool x_stats = x.gn_part && x.gn_groups == 32;
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-5f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr, x.gn_nslab));
   half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
   half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * S); CHECK_ALLOC(vt);
   half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
@@ -243,7 +271,7 @@ int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act out) {
   fa.B = B; fa.H = 1; fa.d = C; fa.Sq = S; fa.Sk = S; fa.scale = 1.f / sqrtf((float)C);
   TSD_TRY(g_attn_core(ctx, fa));
   CatSrc a; a.p0 = ao; a.ld0 = C; a.C0 = C;
-  TSD_TRY(g_linear(ctx, a, M, w.out_proj.w, w.out_proj.Kpad, C, C, w.out_proj.b, x.p, x.ld, 0, out.p, out.ld));
+  TSD_TRY(g_linear(ctx, a, M, w.out_proj.w, w.out_proj.Kpad, C, C, w.out_proj.b, x.p, x.ld, 0, out.p, out.ld, &out, S));
   ctx->arena.release(mark);
   return TSD_OK;
 }
@@ -267,8 +295,10 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
   TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
   Act a[24];
+  // every layer output feeds a GroupNorm (the next block's first norm: 32 groups; the output layer's: 320), so it is
+  // allocated with room for the statistics its producer's epilogue emits
   auto alloc_out = [&](int i, int side, int C) -> int {
-    a[i] = act_alloc(ctx, B, side, side, C);
+    a[i] = act_alloc_gn(ctx, B, side, side, C, i == 23 ? 320 : 32);
     CHECK_ALLOC(a[i].p);
     return TSD_OK;
   };
@@ -305,15 +335,15 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   };
   // encoders (diffusion.mojo:236-250)
   TSD_TRY(alloc_out(1, L, 320));
-  TSD_TRY(g_conv3x3(ctx, x0, u.conv1, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[1].p, a[1].ld));
+  TSD_TRY(g_conv3x3(ctx, x0, u.conv1, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[1].p, a[1].ld, &a[1]));
   TSD_TRY(res(2, cat1(a[1]), L, 0));
   TSD_TRY(attn(3));
   TSD_TRY(alloc_out(4, L1, 320));
-  TSD_TRY(g_conv3x3(ctx, a[3], u.conv4, 2, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[4].p, a[4].ld));
+  TSD_TRY(g_conv3x3(ctx, a[3], u.conv4, 2, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[4].p, a[4].ld, &a[4]));
   TSD_TRY(res(5, cat1(a[4]), L1, 0));
   TSD_TRY(attn(6));
   TSD_TRY(alloc_out(7, L2, 640));
-  TSD_TRY(g_conv3x3(ctx, a[6], u.conv7, 2, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[7].p, a[7].ld));
+  TSD_TRY(g_conv3x3(ctx, a[6], u.conv7, 2, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[7].p, a[7].ld, &a[7]));
   TSD_TRY(res(8, cat1(a[7]), L2, 0));
   TSD_TRY(attn(9));
   // decoders (diffusion.mojo:253-272); skip4 / skip2 are dead (App.A D11): layers 15 and 20 declare
@@ -334,7 +364,8 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   TSD_TRY(attn(23));
   // `UNet_Output_Layer` diffusion.mojo:287-291: GroupNorm(320 groups) -> SiLU -> Conv3x3(320,4)
   Act hf = act_alloc(ctx, B, L, L, 320); CHECK_ALLOC(hf.p);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(a[23]), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld));
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(a[23]), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld,
+                           a[23].gn_groups == 320 ? a[23].gn_part : nullptr, a[23].gn_nslab));
   float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
   TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
   TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));
@@ -348,6 +379,18 @@ static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, 
   const VaeW& v = m->vae;
   const int B = cur.B;
   int pending_up = 0;
+  // groups of the GroupNorm that consumes layer i's output (0: none) - its producer emits the statistics
+  auto next_groups = [&](int i) -> int {
+    for (int j = i + 1; j < n_layers; j++) {
+      const LayerDef& n = layers[j];
+      if (n.kind == L_UP || n.kind == L_SILU) continue;
+      if (n.kind == L_GN) return n.a;
+      if (n.kind == L_RES) return v.res[j].groups;
+      if (n.kind == L_ATTN) return 32;
+      return 0;
+    }
+    return 0;
+  };
   for (int i = 0; i < n_layers; i++) {
     const LayerDef& l = layers[i];
     const bool last = (i == n_layers - 1);
@@ -356,7 +399,9 @@ static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, 
     if (l.kind == L_GN) {
       Act y = act_alloc(ctx, B, cur.H, cur.W, l.b); CHECK_ALLOC(y.p);
       const int silu = (i + 1 < n_layers && layers[i + 1].kind == L_SILU) ? 1 : 0;
-      TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), l.b), B, cur.H * cur.W, l.b, l.a, 1e-5f, 1.f, silu, y.p, y.ld));
+      const bool st = cur.gn_part && cur.gn_groups == l.a && cur.C == l.b;
+      TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), l.b), B, cur.H * cur.W, l.b, l.a, 1e-5f, 1.f, silu, y.p, y.ld,
+                               st ? cur.gn_part : nullptr, cur.gn_nslab));
       cur = y;
       continue;
     }
@@ -378,20 +423,21 @@ static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, 
         *out_side = side; *out_ld = w.Opad;
         return TSD_OK;
       }
-      Act y = act_alloc(ctx, B, side, side, w.Opad); CHECK_ALLOC(y.p);
-      if (l.c == 3) TSD_TRY(g_conv3x3(ctx, cur, w, stride, pad, pad_br, pending_up, nullptr, 0, nullptr, 0, false, y.p, y.ld));
-      else TSD_TRY(g_linear(ctx, cat1(cur), (int64_t)B * side * side, w.w, w.Ipad, w.Opad, w.Ipad, w.b, nullptr, 0, 0, y.p, y.ld));
+      Act y = act_alloc_gn(ctx, B, side, side, w.Opad, next_groups(i)); CHECK_ALLOC(y.p);
+      if (l.c == 3) TSD_TRY(g_conv3x3(ctx, cur, w, stride, pad, pad_br, pending_up, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
+      else TSD_TRY(g_linear(ctx, cat1(cur), (int64_t)B * side * side, w.w, w.Ipad, w.Opad, w.Ipad, w.b, nullptr, 0, 0, y.p, y.ld, &y,
+                            side * side));
       pending_up = 0;
       cur = y;
       continue;
     }
     if (pending_up) TSD_FAIL(TSD_E_STATE, "vae: upsample must be followed by a conv");
     if (l.kind == L_RES) {
-      Act y = act_alloc(ctx, B, cur.H, cur.W, l.b); CHECK_ALLOC(y.p);
+      Act y = act_alloc_gn(ctx, B, cur.H, cur.W, l.b, next_groups(i)); CHECK_ALLOC(y.p);
       TSD_TRY(g_resblock(ctx, cat1(cur), B, cur.H, cur.W, 0, v.res[i], nullptr, 0, y));
       cur = y;
     } else if (l.kind == L_ATTN) {
-      Act y = act_alloc(ctx, B, cur.H, cur.W, l.a); CHECK_ALLOC(y.p);
+      Act y = act_alloc_gn(ctx, B, cur.H, cur.W, l.a, next_groups(i)); CHECK_ALLOC(y.p);
       TSD_TRY(g_vae_attn(ctx, cur, v.attn[i], y));
       cur = y;
     }

@@ -7,28 +7,36 @@
 struct CatSrc {
   const half_t* p0 = nullptr; int ld0 = 0; int C0 = 0;
   const half_t* p1 = nullptr; int ld1 = 0; int C1 = 0;
+  const float* gn_part0 = nullptr; int gn_nslab0 = 0, gn_groups0 = 0;  // producer-emitted GroupNorm statistics of p0
 };
-static inline CatSrc cat1(const Act& a) { CatSrc c; c.p0 = a.p; c.ld0 = a.ld; c.C0 = a.C; return c; }
+static inline CatSrc cat1(const Act& a) {
+  CatSrc c; c.p0 = a.p; c.ld0 = a.ld; c.C0 = a.C;
+  c.gn_part0 = a.gn_part; c.gn_nslab0 = a.gn_nslab; c.gn_groups0 = a.gn_groups;
+  return c;
+}
+// activation whose producer may emit the statistics of the GroupNorm(groups) that will consume it
+Act act_alloc_gn(tsd_ctx* ctx, int B, int H, int W, int C, int groups);
 static inline CatSrc cat2(const Act& a, const Act& b) {
   CatSrc c = cat1(a); c.p1 = b.p; c.ld1 = b.ld; c.C1 = b.C; return c;
 }
 
 // y = conv3x3(x) (+bias) (+rowvec per sample) (+residual); `ups`: x is read through a nearest-2x upsample.
 int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, int pad_br, int ups,
-              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy);
+              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy,
+              Act* stat = nullptr);  // stat: the output tensor's Act when GroupNorm statistics are wanted
 // y[M][N] = A[M][K] . W^T (+bias) (+residual) ; A may be a concat view
 int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
-             const half_t* res, int ldr, int epi_extra, void* y, int ldy);
+             const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat = nullptr, int rows_per_sample = 0);
 
 int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
-               int tld, Act out);
+               int tld, Act& out);
 struct CtxKV {  // projected context keys (token-major) and values (channel-major) of one attention block
   const half_t* K = nullptr; int ldk = 0; int64_t sK = 0;
   const half_t* Vt = nullptr; int ldvt = 0; int64_t sVt = 0;
 };
-int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act out,
+int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16, int T, int Tp, Act& out,
                 const CtxKV* pre = nullptr);
-int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act out);
+int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act& out);
 int g_attn_core(tsd_ctx* ctx, const AttnArgs& fa);
 int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& in_proj, half_t* qk, half_t* vt, int Sp);
 

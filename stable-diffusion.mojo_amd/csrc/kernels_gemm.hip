@@ -37,6 +37,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct GemmK {
   const half_t* A0; const half_t* A1; const half_t* Wt; const half_t* R; const half_t* zeros;
@@ -48,6 +49,7 @@ struct GemmK {
   int Hs, Ws, Ho, Wo, Cin, stride, pad, ups;
   int epi, tiles_n, xcd_n;
   float out_scale;
+  float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
 #ifdef TSD_GEMM_TS
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
 #endif
@@ -451,6 +453,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       asm volatile("" ::: "memory");
       TS_MARK(3);
       float* ep = (float*)smem + wave * (32 * EPP);
+      // EPI_GNSTATS: per-channel (sum, sumsq) of the ROUNDED output over this wave's rows, lane j < BNw/2 owning columns
+      // 2j and 2j+1; reduced to the consumer GroupNorm's groups at the end (replaces its statistics pass).
+      const bool gn_on = (epi & EPI_GNSTATS) && m0 + wm * BMw < p.M;
 #pragma unroll
       for (int pass = 0; pass < FM / 2; pass++) {
 #pragma unroll
@@ -519,6 +524,37 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (half_t)v[j];
             *(h8*)((half_t*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + n) = o;
+            if (gn_on) *(h8*)(ep + r * EPP + c * 8) = o;  // back into the slot just read (same-wave LDS ops are ordered)
+          }
+        }
+        if (gn_on) {
+          // one 32-row slab per pass, whatever the tile shape: the partials (and so the normalised tensor) are bitwise
+          // independent of the tile configuration, hence of the batch size
+          float cs1[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+          if (lane < BNw / 2) {
+            const char* colp = (const char*)(ep + (lane >> 2) * 8) + (lane & 3) * 4;
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) {
+              const h2 hv = *(const h2*)(colp + r * (EPP * 4));
+              const float f0 = (float)hv[0], f1 = (float)hv[1];
+              cs1[0] += f0; cs2[0] += f0 * f0;
+              cs1[1] += f1; cs2[1] += f1 * f1;
+            }
+          }
+          float* cst = ep;  // [BNw][2] (the transposed rows are dead now)
+          if (lane < BNw / 2) *(f4*)(cst + 4 * lane) = f4{cs1[0], cs2[0], cs1[1], cs2[1]};
+          const int mrow = m0 + wm * BMw + pass * 32;
+          const int b = mrow / p.gn_hw, slab = (mrow - b * p.gn_hw) >> 5;
+          float* obase = p.gn_part + ((long long)b * p.gn_nslab + slab) * p.gn_G * 2;
+          for (int gi = lane; gi * p.gn_cpg < BNw; gi += 64) {  // up to BNw groups in the slice (one channel per group)
+            const int colbase = n0 + wn * BNw + gi * p.gn_cpg;
+            if (colbase >= p.N) break;
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < p.gn_cpg; k++) {
+              s1 += cst[(gi * p.gn_cpg + k) * 2];
+              s2 += cst[(gi * p.gn_cpg + k) * 2 + 1];
+            }
+            *(f2*)(obase + (colbase / p.gn_cpg) * 2) = f2{s1, s2};
           }
         }
       }
@@ -722,6 +758,27 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv) {
   return n160 ? 7 : 10;
 }
 
+// rows / columns of one wave's output sub-tile for tile configuration `id` (FM*16, FN*16)
+static void cfg_wave_tile(int id, int* bmw, int* bnw) {
+  switch (id) {
+    case 0: case 5: case 11: *bmw = 64; *bnw = 80; break;
+    case 1: case 6: case 7: *bmw = 32; *bnw = 80; break;
+    case 2: case 8: case 13: *bmw = 64; *bnw = 64; break;
+    case 3: case 9: case 10: *bmw = 32; *bnw = 64; break;
+    default: *bmw = 0; *bnw = 0; break;  // thin / experimental tiles: no epilogue statistics
+  }
+}
+// EPI_GNSTATS geometry for a launch of this shape: slabs per sample (rows_per_sample / wave rows), or 0 when the tile
+// it would run with cannot emit statistics for `groups` groups over N channels.
+int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups) {
+  if (groups <= 0 || N % groups || (N & 7) || batch != 1) return 0;
+  int bmw, bnw;
+  cfg_wave_tile(choose_cfg(M, N, K, batch, conv != 0), &bmw, &bnw);
+  const int cpg = N / groups;
+  if (!bmw || bnw % cpg || rows_per_sample % bmw || M % rows_per_sample) return 0;
+  return rows_per_sample / 32;  // one slab per 32-row epilogue pass, independent of the tile shape
+}
+
 template <bool CONV>
 static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
   const int id = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV);
@@ -876,6 +933,11 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     if (a_bytes > lim || w_bytes > lim)
       TSD_FAIL(TSD_E_SHAPE, "gemm: operand slice of %lld / %lld bytes exceeds the 2 GiB addressing window", a_bytes, w_bytes);
   }
+  if (a.epi & EPI_GNSTATS) {
+    if ((a.epi & (EPI_GEGLU | EPI_OUT_F32)) || !a.gn_part ||
+        a.gn_nslab != gemm_gnstats_slabs(a.M, a.N, a.K, a.batch, a.conv, a.gn_rows_per_sample, a.gn_groups) || a.gn_nslab <= 0)
+      TSD_FAIL(TSD_E_ARG, "gemm: GroupNorm statistics requested for a shape/tile that cannot emit them");
+  }
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, a.conv ? KC_CONV : KC_GEMM, a.M, a.N, a.K, a.batch);
   GemmK k;
@@ -887,5 +949,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.M = a.M; k.N = a.N; k.K = a.K;
   k.Hs = a.Hs; k.Ws = a.Ws; k.Ho = a.Ho; k.Wo = a.Wo; k.Cin = a.Cin; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
+  k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
+  k.gn_nslab = a.gn_nslab;
   return a.conv ? dispatch<true>(ctx, k, a.batch) : dispatch<false>(ctx, k, a.batch);
 }

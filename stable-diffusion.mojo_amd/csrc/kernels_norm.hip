@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
     const int g = g0 + (tid >> 3), sl = tid & 7;
     double t1 = 0.0, t2 = 0.0;
     if (g < p.G)
+#pragma unroll 4
       for (int s = sl; s < p.nslab; s += 8) {
         const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
         t1 += (double)o[0];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 }
 
 int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
-                     int silu, half_t* y, int ldy) {
+                     int silu, half_t* y, int ldy, const float* pre_part, int pre_nslab) {
   if (C % 8 || C % groups || C > 256 * 8 * GN_MAX_CPT)
     TSD_FAIL(TSD_E_SHAPE, "groupnorm: C=%d groups=%d unsupported", C, groups);
   const int C0 = src.x1 ? src.C0 : C;
@@ -199,14 +200,19 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 64));  // <= 64 slabs: every apply block re-reduces them
   k.nslab = ceil_div(HW, k.slab_pixels);
   k.apply_pixels = 2 * GN_UNROLL * PL;
-  k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
+  // statistics already emitted by the producer's epilogue (EPI_GNSTATS, same [B][nslab][G][2] layout): no partial pass
+  const bool have_stats = pre_part != nullptr && pre_nslab > 0;
+  if (have_stats) { k.partial = const_cast<float*>(pre_part); k.nslab = pre_nslab; }
+  else k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
   k.stats = arena_alloc<float>(ctx, (int64_t)B * groups * 2);
   if (!k.partial || !k.stats) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
   k.eps = eps; k.gamma = gamma; k.silu = silu; k.y = y; k.ldy = ldy;
   if (!ctx->launch()) return TSD_OK;
-  ProfScope prof(ctx, KC_GROUPNORM);
-  hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
-  HIP_TRY(hipGetLastError());
+  ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
+  if (!have_stats) {
+    hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
                      ctx->stream, k);
   HIP_TRY(hipGetLastError());
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
 int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy) {
   if (C % 8 || C > 64 * 8 * LN_MAX_CH) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d unsupported", C);
   if (!ctx->launch()) return TSD_OK;
-  ProfScope prof(ctx, KC_LAYERNORM);
+  ProfScope prof(ctx, KC_LAYERNORM, (int)rows, C, 0, 1);
   hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps, y,
                      ldy);
   HIP_TRY(hipGetLastError());
