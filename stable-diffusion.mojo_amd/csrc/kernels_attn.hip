@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "lds_dma.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -93,51 +94,47 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   }
 
   // ---- per-thread DMA slots -------------------------------------------------------------------
-  // K tile: slot = row*KPITCH + pos ; LDS row `row` holds key k0 + pi(row), pi swaps bits 2 and 3.
-  int k_key[K_PW]; int k_off[K_PW]; bool k_data[K_PW];
+  // Tiles go global -> LDS through buffer descriptors (lds_dma.h): a 32-bit byte offset per DMA instruction, the
+  // tile position in the scalar offset, zero fill from the range check - no address VALU in the loop.
+  // K tile: slot = row*KPITCH + pos ; LDS row `row` holds key k0 + pi(row), pi swaps bits 2 and 3.  Keys >= Sk fall
+  // outside the descriptor (it ends after row Sk-1) and read as zeros; their scores are masked below anyway.
+  const rsrc_t rK = make_rsrc(Kb, p.Sk * p.ldk * 2);
+  unsigned k_voff[K_PW];
 #pragma unroll
   for (int i = 0; i < K_PW; i++) {
     const int slot = (wave + 4 * i) * 64 + lane;
     const int row = slot / KPITCH, pos = slot - row * KPITCH;
     const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
-    k_key[i] = key;
-    k_off[i] = key * p.ldk + pos * 8;
-    k_data[i] = pos < DCH;
+    k_voff[i] = pos < DCH ? (unsigned)(key * p.ldk + pos * 8) * 2 : PAD_OFF;
   }
-  // V^T tile: LDS row R (= channel within head) x 8 chunks; phys pos holds logical chunk pos ^ ((R>>1)&7)
-  int v_chunk[V_PW]; long long v_off[V_PW]; bool v_data[V_PW]; bool v_one[V_PW];
+  // V^T tile: LDS row R (= channel within head) x 8 chunks; phys pos holds logical chunk pos ^ ((R>>1)&7).  A row
+  // is a run of keys inside a longer pitch, so a chunk past the last valid key is NOT out of the descriptor's
+  // linear range: the last tile uses its own offset set with those chunks padded.
+  const rsrc_t rV = make_rsrc(Vb);
+  const int ntiles = (p.Sk + 63) >> 6;
+  unsigned v_voff[V_PW], v_voff_last[V_PW];
 #pragma unroll
   for (int i = 0; i < V_PW; i++) {
     const int R = (wave + 4 * i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((R >> 1) & 7);
-    v_chunk[i] = c;
-    v_off[i] = (long long)R * p.ldvt + c * 8;
-    v_data[i] = R < D;
-    v_one[i] = ONES_ROW && R == D;
+    v_voff[i] = R < D ? (unsigned)(R * p.ldvt + c * 8) * 2 : PAD_OFF;
+    v_voff_last[i] = ((ntiles - 1) * 64 + c * 8 + 8 <= p.Skv) ? v_voff[i] : PAD_OFF;
   }
-  const half_t* zsrc = p.zeros;
 
   auto stage = [&](int t, int buf) {
     char* sK = smem + buf * BUF_BYTES;
     char* sV = sK + K_BYTES;
     const int k0 = t * 64;
+    const bool last = t == ntiles - 1;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < K_PW; i++) {
       const int j = wave + 4 * i;
-      if (K_INSTR % 4 == 0 || j < K_INSTR) {
-        const bool ok = k_data[i] && (k0 + k_key[i] < p.Sk);
-        const half_t* src = ok ? Kb + (long long)k0 * p.ldk + k_off[i] : zsrc;
-        glds16a(src, sK + j * 1024);
-      }
+      if (K_INSTR % 4 == 0 || j < K_INSTR) blds16(rK, k_voff[i], (unsigned)(k0 * p.ldk) * 2, sK + j * 1024);
     }
 #pragma unroll
     for (int i = 0; i < V_PW; i++) {
       const int j = wave + 4 * i;
-      if (V_INSTR % 4 == 0 || j < V_INSTR) {
-        const bool ok = v_data[i] && (k0 + v_chunk[i] * 8 + 8 <= p.Skv);
-        const half_t* src = ok ? Vb + k0 + v_off[i] : zsrc;
-        glds16a(src, sV + j * 1024);
-      }
+      if (V_INSTR % 4 == 0 || j < V_INSTR) blds16(rV, last ? v_voff_last[i] : v_voff[i], (unsigned)k0 * 2, sV + j * 1024);
     }
   };
 
@@ -157,7 +154,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int vkey = (lane >> 1) & 7;  // swizzle key of V^T row (db*32 + l31)
-  const int ntiles = (p.Sk + 63) >> 6;
 
   // S^T = K . Q^T of one 64-key tile: two 32-key blocks
   auto qk = [&](int buf, f16v& s0, f16v& s1) {

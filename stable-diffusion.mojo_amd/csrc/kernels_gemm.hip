@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "lds_dma.h"
 
 #ifndef TSD_GEMM_PIN
 #define TSD_GEMM_PIN 1
@@ -54,19 +55,6 @@ struct GemmK {
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
 #endif
 };
-
-// LDS-DMA through a buffer descriptor: 16 B per lane from (descriptor base + soff + voff) straight into LDS at
-// (wave-uniform l) + lane*16.  Lanes whose offset fails the descriptor's range check write ZEROS (verified by
-// scripts/micro/buflds_oob.hip, which also shows soff takes part in the check) - conv zero padding rides on that:
-// out-of-image taps carry the offset PAD_OFF, beyond the 2 GiB window every descriptor here spans.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr unsigned PAD_OFF = 0x80000000u;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffff0, 0x00020000);
-}
-__device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, unsigned soff, void* l) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
-}
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float c = 0.7978845608028654f;  // sqrt(2/pi), helpers/utils.mojo:1914
