@@ -243,36 +243,75 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem_sl[];
   float* xs = (float*)smem_sl;  // [B][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < B * K; i += 256) {
-    const int b = i / K, k = i - b * K;
-    float v = x[(int64_t)b * ldx + k];
-    xs[i] = silu_in ? silu_f(v) : v;
-  }
-  __syncthreads();
-  const int n_per_block = 16;
-  for (int j = wave; j < n_per_block; j += 4) {
-    const int n = blockIdx.x * n_per_block + j;
-    if (n >= N) break;
-    float acc[SL_MAXB];
+  // activations -> LDS (with the fused SiLU): batches of 8 independent 16-B loads per thread (K % 4 == 0), so the
+  // staging costs a couple of L2 round trips instead of one per element
+  const int nvec = (B * K) >> 2;
+  for (int i0 = tid; i0 < nvec; i0 += 256 * 8) {
+    f4 v[8];
 #pragma unroll
-    for (int b = 0; b < SL_MAXB; b++) acc[b] = 0.f;
-    const half_t* wr = w + (int64_t)n * ldw;
-    for (int k0 = lane * 8; k0 < K; k0 += 512) {
-      const h8 wv = *(const h8*)(wr + k0);
-#pragma unroll
-      for (int b = 0; b < SL_MAXB; b++) {
-        if (b < B) {
-          const f4 x0 = *(const f4*)(xs + b * K + k0), x1 = *(const f4*)(xs + b * K + k0 + 4);
-          acc[b] += (float)wv[0] * x0[0] + (float)wv[1] * x0[1] + (float)wv[2] * x0[2] + (float)wv[3] * x0[3] +
-                    (float)wv[4] * x1[0] + (float)wv[5] * x1[1] + (float)wv[6] * x1[2] + (float)wv[7] * x1[3];
-        }
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u * 256;
+      if (i < nvec) {
+        const int e = i * 4, b = e / K, k = e - b * K;
+        v[u] = *(const f4*)(x + (int64_t)b * ldx + k);
       }
     }
 #pragma unroll
-    for (int b = 0; b < SL_MAXB; b++) {
-      if (b < B) {
-        const float s = wave_sum(acc[b]);
-        if (lane == 0) y[(int64_t)b * ldy + n] = s + (bias ? bias[n] : 0.f);
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u * 256;
+      if (i < nvec) {
+        if (silu_in) v[u] = f4{silu_f(v[u][0]), silu_f(v[u][1]), silu_f(v[u][2]), silu_f(v[u][3])};
+        *(f4*)(xs + i * 4) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  // Each wave owns 4 of the block's 16 output columns.  All of its weight loads (4 columns x up to 4 K-slices of
+  // 512) are issued before any arithmetic, so the block pays one HBM round trip instead of one per slice.
+  const int n_per_block = 16;
+  constexpr int SL_COLS = 4, SL_KIT = 4;  // K <= 2048 in one shot; longer rows loop
+  for (int kbase = 0; kbase < K; kbase += 512 * SL_KIT) {
+    h8 wv[SL_COLS][SL_KIT];
+#pragma unroll
+    for (int j = 0; j < SL_COLS; j++) {
+      const int n = min(blockIdx.x * n_per_block + wave + 4 * j, N - 1);
+      const half_t* wr = w + (int64_t)n * ldw;
+#pragma unroll
+      for (int it = 0; it < SL_KIT; it++) {
+        const int k0 = kbase + it * 512 + lane * 8;
+        wv[j][it] = k0 < K ? *(const h8*)(wr + k0) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SL_COLS; j++) {
+      const int n = blockIdx.x * n_per_block + wave + 4 * j;
+      float acc[SL_MAXB];
+#pragma unroll
+      for (int b = 0; b < SL_MAXB; b++) acc[b] = 0.f;
+#pragma unroll
+      for (int it = 0; it < SL_KIT; it++) {
+        const int k0 = kbase + it * 512 + lane * 8;
+        if (k0 < K) {
+#pragma unroll
+          for (int b = 0; b < SL_MAXB; b++) {
+            if (b < B) {
+              const f4 x0 = *(const f4*)(xs + b * K + k0), x1 = *(const f4*)(xs + b * K + k0 + 4);
+              const h8 q = wv[j][it];
+              acc[b] += (float)q[0] * x0[0] + (float)q[1] * x0[1] + (float)q[2] * x0[2] + (float)q[3] * x0[3] +
+                        (float)q[4] * x1[0] + (float)q[5] * x1[1] + (float)q[6] * x1[2] + (float)q[7] * x1[3];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < SL_MAXB; b++) {
+        if (b < B) {
+          const float s = wave_sum(acc[b]);
+          if (lane == 0 && n < N) {
+            float* yp = y + (int64_t)b * ldy + n;
+            *yp = kbase == 0 ? s + (bias ? bias[n] : 0.f) : *yp + s;
+          }
+        }
       }
     }
   }
@@ -280,9 +319,9 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
                         int N, int silu_in, float* y, int ldy) {
   if (B > SL_MAXB) TSD_FAIL(TSD_E_SHAPE, "small_linear: B=%d > %d", B, SL_MAXB);
-  if (K % 8) TSD_FAIL(TSD_E_SHAPE, "small_linear: K=%d not a multiple of 8", K);
+  if (K % 8 || ldx % 4) TSD_FAIL(TSD_E_SHAPE, "small_linear: K=%d must be a multiple of 8 (ldx=%d of 4)", K, ldx);
   if (!ctx->launch()) return TSD_OK;
-  ProfScope prof(ctx, KC_SMALL_LINEAR);
+  ProfScope prof(ctx, KC_SMALL_LINEAR, B, N, K, 1);
   const size_t lds = (size_t)B * K * sizeof(float);
   static bool attr = false;
   if (!attr) {
