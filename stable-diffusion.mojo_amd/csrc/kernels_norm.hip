@@ -270,12 +270,64 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
   }
 }
 
+// UNet token widths (C = 40 * LPR, LPR a power of two <= 32): LPR lanes share a row, 5 chunks of 8 channels each, so a
+// wave normalises 64 / LPR rows at once with every lane busy and five independent 16-B loads in flight per lane
+// (the one-wave-per-row kernel above leaves 24 of 64 lanes idle at C = 320 and moves 640 B per wave).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_layernorm_grp(const half_t* __restrict__ x, int64_t rows, int ldx, float eps,
+                                                       half_t* __restrict__ y, int ldy) {
+  constexpr int RPW = 64 / LPR, C = 40 * LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool ok = row < rows;
+  const half_t* xr = x + (ok ? row : rows - 1) * ldx;
+  h8 v[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) v[q] = *(const h8*)(xr + (sub + q * LPR) * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 5; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += (float)v[q][j];
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 5; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float d = (float)v[q][j] - mu;
+      ss += d * d;
+    }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float r = 1.f / (sqrtf(ss / (float)C) + eps);
+  if (!ok) return;
+  half_t* yr = y + row * ldy;
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (half_t)(((float)v[q][j] - mu) * r);
+    *(h8*)(yr + (sub + q * LPR) * 8) = o;
+  }
+}
+
 int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy) {
   if (C % 8 || C > 64 * 8 * LN_MAX_CH) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d unsupported", C);
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_LAYERNORM, (int)rows, C, 0, 1);
-  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps, y,
-                     ldy);
+  if (C == 320 || C == 640 || C == 1280) {
+    const int lpr = C / 40, rows_per_block = 4 * (64 / lpr);
+    const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+    if (lpr == 8) hipLaunchKernelGGL(k_layernorm_grp<8>, grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy);
+    else if (lpr == 16) hipLaunchKernelGGL(k_layernorm_grp<16>, grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy);
+    else hipLaunchKernelGGL(k_layernorm_grp<32>, grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy);
+  } else {
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps, y,
+                       ldy);
+  }
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
