@@ -66,7 +66,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 #ifdef TSD_GEMM_TS
 static unsigned long long* g_ts = nullptr;
-#define TS_MARK(i) do { if (p.ts && threadIdx.x == 0) p.ts[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TS_MARK(i) do { if (p.ts && threadIdx.x == 0) { p.ts[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0 || (i) == 4) p.ts[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + ((i) == 0 ? 5 : 6)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define TS_MARK(i) do { } while (0)
 #endif
@@ -826,12 +826,19 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
     HIP_TRY(hipMemcpy(h.data(), dts, (size_t)nblk * 64, hipMemcpyDeviceToHost));
     hipFree(dts);
     unsigned long long tmin = ~0ull, tmax = 0; int n = 0;
-    for (int b = 0; b < nblk; b++) if (h[b * 8]) { n++; tmin = std::min(tmin, h[b * 8]); tmax = std::max(tmax, h[b * 8 + 4]); }
-    fprintf(stderr, "[ts] blocks=%d kernel span=%llu ticks\n", n, tmax - tmin);
+    for (int b = 0; b < nblk; b++) if (h[b * 8]) { n++; tmin = std::min(tmin, h[b * 8 + 5]); tmax = std::max(tmax, h[b * 8 + 6]); }
+    fprintf(stderr, "[ts] blocks=%d span first-start..last-end = %.2f us (100 MHz realtime)\n", n, (tmax - tmin) * 0.01);
+    {
+      std::vector<double> st, en;
+      for (int b = 0; b < nblk; b++) if (h[b * 8]) { st.push_back((h[b * 8 + 5] - tmin) * 0.01); en.push_back((h[b * 8 + 6] - tmin) * 0.01); }
+      std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+      fprintf(stderr, "[ts] block start (us): med %.2f p90 %.2f max %.2f ; block end (us): min %.2f med %.2f max %.2f\n",
+              st[st.size() / 2], st[st.size() * 9 / 10], st.back(), en.front(), en[en.size() / 2], en.back());
+    }
     const char* nm[5] = {"start-after-first-block", "prologue", "main loop", "drain+barrier", "epilogue"};
-    for (int ph = 0; ph < 5; ph++) {
+    for (int ph = 1; ph < 5; ph++) {
       std::vector<unsigned long long> d;
-      for (int b = 0; b < nblk; b++) if (h[b * 8]) d.push_back(ph == 0 ? h[b * 8] - tmin : h[b * 8 + ph] - h[b * 8 + ph - 1]);
+      for (int b = 0; b < nblk; b++) if (h[b * 8]) d.push_back(h[b * 8 + ph] - h[b * 8 + ph - 1]);
       std::sort(d.begin(), d.end());
       fprintf(stderr, "[ts] %-24s min %8llu  med %8llu  p90 %8llu  max %8llu\n", nm[ph], d.front(), d[d.size() / 2], d[d.size() * 9 / 10], d.back());
     }
