@@ -134,10 +134,18 @@ def main():
     # weights: rank 0 random-initialises on the device; other ranks receive the packed blob over RCCL
     unet = tsd.Diffusion(seed=SEED if rank == 0 else None, ctx=ctx)
     dec = None if args.no_decode else tsd.Decoder(seed=SEED if rank == 0 else None, ctx=ctx)
-    bcast_s, bcast_bytes = 0.0, 0
+    bcast_s, bcast_bytes, bcast_how = 0.0, 0, "none (single GPU)"
     if world > 1:
-        bcast_s, bcast_bytes = broadcast_weights([unet.model] + ([dec.model] if dec is not None else []), rank, world,
-                                                 local_rank)
+        models = [unet.model] + ([dec.model] if dec is not None else [])
+        try:
+            bcast_s, bcast_bytes = broadcast_weights(models, rank, world, local_rank)
+            bcast_how = "rccl broadcast of the packed blobs from rank 0"
+        except Exception as e:  # the timed path does not depend on it: the device RNG gives every rank the same weights
+            print(f"rank {rank}: weight broadcast failed ({e!r}); initialising from the shared seed instead", file=sys.stderr)
+            if rank != 0:
+                for m in models:
+                    m.init_random(SEED)
+            bcast_how = "fallback: every rank regenerated the weights from the shared seed (broadcast failed)"
 
     # synthetic inputs: global batch of world*B independent prompts, this rank's contiguous shard
     lo, hi = shard_range(world * B, rank, world)
@@ -248,7 +256,7 @@ def main():
                 "images_per_s": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
             "event_ms_per_step": round(ev_ms / K, 4), "output_finite": finite,
             "frac_of_fp16_mfma_peak_whole_step": round(whole_frac, 4),
-            "weight_broadcast_s": round(bcast_s, 4), "weight_broadcast_bytes": bcast_bytes,
+            "weight_broadcast_s": round(bcast_s, 4), "weight_broadcast_bytes": bcast_bytes, "weight_broadcast": bcast_how,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
