@@ -160,7 +160,7 @@ int tsd_vae_attention_block_f32(tsd_ctx* ctx, const float* x, int C, int H, int 
 
 /* ---- module level: device-resident weights (the measured path) ------------------------ */
 
-typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3 } tsd_model_kind;
+typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4 } tsd_model_kind;
 
 /* Parameter inventory in struct-field DFS order: `Diffusion`
  * diffusion.mojo:299-302, `Decoder` vae.mojo:194-219, `Encoder` vae.mojo:94-112.  No GPU needed. */
@@ -190,6 +190,13 @@ int tsd_decoder_forward(tsd_model* m, const float* latents, int B, int L, float*
 /* `Encoder.forward` vae.mojo:131-159 (+ metrics_evals :118-129), batched.  images [B,3,S,S] in
  * [-1,1], noise [B,4,S/8,S/8] -> latents [B,4,S/8,S/8]. */
 int tsd_encoder_forward(tsd_model* m, const float* images, const float* noise, int B, int S, float* latents);
+
+/* `CLIP.forward` clip.mojo:90-109 (the step before the hot path), intended semantics
+ * (App.A D3/D8/D15/D20): tokens [B][T] int32 ids (T <= 77; rows are zero-padded to 77 like clip.mojo:91-93)
+ * -> context [B][77][768] fp32, the `context` input of tsd_diffusion_forward / tsd_session_upload.
+ * Token embedding + learned position table, 12 x (LayerNorm, causal 12-head self-attention, +res, LayerNorm,
+ * Linear 768->3072, quick-GELU x*sigmoid(1.702x), Linear 3072->768, +res), final LayerNorm. */
+int tsd_clip_forward(tsd_model* m, const int32_t* tokens, int B, int T, float* context);
 /* pipeline.mojo:127 `rescale((-1,1),(0,255),clamp=True)` (helpers/utils.mojo:577-597). */
 int tsd_rescale_images_f32(tsd_ctx* ctx, const float* x, int64_t n, float* y);
 

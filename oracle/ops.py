@@ -39,6 +39,16 @@ def gelu_tanh(x):
     return x * (0.5 * (1.0 + np.tanh(c * (x + x.dtype.type(0.044715) * x ** 3))))
 
 
+def quick_gelu(x):
+    """CLIP's activation, intended form x * sigmoid(1.702 x) (clip.mojo:49-50; literal aliasing bug App.A D15)."""
+    return x / (1.0 + np.exp(-x * x.dtype.type(1.702)))
+
+
+def embedding(tokens, table):
+    """`Embedding.forward` helpers/utils.mojo:2032-2046, intended out[t] = W[token[t]] (App.A D3)."""
+    return table[np.asarray(tokens, dtype=np.int64)]
+
+
 def time_embedding(t, sem=DEFAULT, dtype=np.float32):
     """`get_time_embedding` helpers/utils.mojo:353-370 -> (320,).
 

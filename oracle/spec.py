@@ -161,7 +161,26 @@ def encoder_params() -> List[Param]:
     return _vae_params(ENCODER_LAYERS)
 
 
-MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3}
+def clip_params() -> List[Param]:
+    """`CLIP.__init__` clip.mojo:74-88: ClipEmbedding(49408, 768, 77) + 12 x ClipPlayer(12, 768) + LayerNorm(768)
+    (the reference's LayerNorm has no parameters, helpers/utils.mojo:2052-2061).
+
+    Synthetic init (weights are inputs, App.A rule 3): the token table is N(0,1) in the reference
+    (`init_weights_normal(0,1)` helpers/utils.mojo:2025) -> U(+-sqrt(3)) here (same variance, counter RNG); the
+    position table is zero-initialised there (clip.mojo:13-15) -> U(+-0.02) here so parity tests exercise the add."""
+    out: List[Param] = []
+    out.append(Param("embedding.token.weight", (49408, 768), "lin_w", float(np.sqrt(3.0))))
+    out.append(Param("embedding.position", (77 * 768,), "lin_b", 0.02))
+    for i in range(1, 13):
+        n = f"player{i}"
+        _lin(out, n + ".layer2.in_proj", 768, 3 * 768)   # Self_Attention(12, 768): in_bias defaults to True
+        _lin(out, n + ".layer2.out_proj", 768, 768)
+        _lin(out, n + ".layer4", 768, 4 * 768)
+        _lin(out, n + ".layer5", 4 * 768, 768)
+    return out
+
+
+MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4}
 
 
 def tensor_id(model: str, index: int) -> int:
@@ -170,8 +189,8 @@ def tensor_id(model: str, index: int) -> int:
 
 
 def init_params(model: str, seed: int, only_used=False):
-    """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder') -> {name: array}."""
-    plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params}[model]()
+    """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder'|'clip') -> {name: array}."""
+    plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params, "clip": clip_params}[model]()
     out = {}
     for i, p in enumerate(plist):
         if only_used and not p.used:

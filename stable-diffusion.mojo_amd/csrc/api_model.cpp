@@ -4,6 +4,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include "graph.h"
 
 #define NOTNULL(p) \
@@ -89,6 +91,25 @@ extern "C" int tsd_encoder_forward(tsd_model* m, const float* images, const floa
     TSD_TRY(h2d(ctx, dn, noise, nl * 4));
     TSD_TRY(g_encoder_forward(m, di, dn, B, S, dl));
     return d2h(ctx, latents, dl, nl * 4);
+  });
+}
+
+extern "C" int tsd_clip_forward(tsd_model* m, const int32_t* tokens, int B, int T, float* context) {
+  NOTNULL(m); NOTNULL(tokens); NOTNULL(context);
+  if (m->kind != TSD_MODEL_CLIP) TSD_FAIL(TSD_E_ARG, "tsd_clip_forward: model is not a CLIP");
+  if (B <= 0 || T <= 0 || T > 77) TSD_FAIL(TSD_E_SHAPE, "clip: B=%d T=%d (1..77 tokens)", B, T);
+  tsd_ctx* ctx = m->ctx;
+  std::vector<int32_t> padded((size_t)B * 77, 0);  // clip.mojo:91-93: a zero row of 77 ids, the prompt's ids in front
+  for (int b = 0; b < B; b++)
+    for (int t = 0; t < T; t++) padded[(size_t)b * 77 + t] = tokens[(size_t)b * T + t];
+  return run_model(m, [&]() -> int {
+    const int64_t no = (int64_t)B * 77 * 768;
+    int* dt = arena_alloc<int>(ctx, (int64_t)B * 77);
+    float* dout = arena_alloc<float>(ctx, no);
+    if (!dt || !dout) TSD_FAIL(TSD_E_ALLOC, "workspace arena exhausted");
+    TSD_TRY(h2d(ctx, dt, padded.data(), padded.size() * sizeof(int32_t)));
+    TSD_TRY(g_clip_forward(m, dt, B, dout));
+    return d2h(ctx, context, dout, no * 4);
   });
 }
 

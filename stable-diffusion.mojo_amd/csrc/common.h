@@ -184,6 +184,10 @@ int launch_pad_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, int t, int
 int launch_upsample_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, float* y);
 int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols, float* y);
 int launch_softmax_rows_f16(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld);  // in place
+int launch_softmax_rows_f16_causal(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld, int period, int zero_to);
+int launch_clip_embed(tsd_ctx* ctx, const int* tokens, const half_t* table, int n_vocab, int D, const float* pos, int B,
+                      int T, half_t* y);
+int launch_quick_gelu_f16(tsd_ctx* ctx, half_t* x, int64_t n);
 int launch_time_embedding(tsd_ctx* ctx, const float* t_dev, float t_scalar, int B, float* out);  // out [B][320]; t_dev NULL -> scalar
 int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
                         int N, int silu_in, float* y, int ldy);

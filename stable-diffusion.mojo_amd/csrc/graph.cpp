@@ -472,3 +472,73 @@ int g_encoder_forward(tsd_model* m, const float* images_chw, const float* noise_
   TSD_TRY(launch_encoder_sample(ctx, mom, B, L * L, 8, noise_chw, latents_chw));
   return TSD_OK;
 }
+
+// `CLIP.forward` clip.mojo:90-109 on device token ids [B][77] -> fp32 [B][77][768].
+// 77 tokens x 12 heads of 64: the attention core runs unfused per sample (head-batched score GEMM -> masked row
+// softmax -> head-batched P.V GEMM with keys zero-padded to 128); it is executed once per prompt, off the denoise loop.
+int g_clip_forward(tsd_model* m, const int* tokens_dev, int B, float* out_f32) {
+  tsd_ctx* ctx = m->ctx;
+  const ClipW& c = m->clip;
+  const int T = 77, D = 768, H = 12, dh = 64, Tp = 128;
+  const int64_t M = (int64_t)B * T;
+  half_t* x = arena_alloc<half_t>(ctx, M * D); CHECK_ALLOC(x);
+  half_t* x2 = arena_alloc<half_t>(ctx, M * D); CHECK_ALLOC(x2);
+  // the GEMM wants N % 4 == 0: the 77 keys are addressed as 80, so the token-major buffers carry 3 zero rows of slack
+  // behind the last sample (rows 77..79 of a sample are the next sample's first rows: finite, and masked / multiplied
+  // by exactly-zero probabilities)
+  const int Tn = 80;
+  half_t* ln = arena_alloc<half_t>(ctx, (M + 3) * D); CHECK_ALLOC(ln);
+  half_t* qk = arena_alloc<half_t>(ctx, (M + 3) * 2 * D); CHECK_ALLOC(qk);
+  TSD_TRY(zero_async(ctx, ln + M * D, (size_t)3 * D * sizeof(half_t)));
+  TSD_TRY(zero_async(ctx, qk + M * 2 * D, (size_t)3 * 2 * D * sizeof(half_t)));
+  half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * D * Tp); CHECK_ALLOC(vt);
+  half_t* sc = arena_alloc<half_t>(ctx, (int64_t)H * T * Tp); CHECK_ALLOC(sc);
+  half_t* ao = arena_alloc<half_t>(ctx, M * D); CHECK_ALLOC(ao);
+  half_t* ff = arena_alloc<half_t>(ctx, M * 4 * D); CHECK_ALLOC(ff);
+  TSD_TRY(zero_async(ctx, vt, (size_t)B * D * Tp * sizeof(half_t)));  // key padding 77..127 stays zero
+  TSD_TRY(launch_clip_embed(ctx, tokens_dev, c.tok, 49408, D, c.pos, B, T, x));  // clip.mojo:17-20
+  CatSrc a;
+  for (int l = 0; l < 12; l++) {
+    const ClipLayerW& w = c.layer[l];
+    // ---- LN -> causal self-attention -> + residue (clip.mojo:37-43) ----
+    TSD_TRY(launch_layernorm(ctx, x, M, D, D, 1e-5f, ln, D));
+    a.p0 = ln; a.ld0 = D; a.C0 = D;
+    TSD_TRY(g_linear(ctx, a, M, w.in_proj.w, w.in_proj.Kpad, 2 * D, D, w.in_proj.b, nullptr, 0, 0, qk, 2 * D));  // q, k
+    {  // V^T[b] = W_v . ln_b^T + b_v  -> [B][768][128]
+      GemmArgs g;
+      g.A0 = w.in_proj.w + (int64_t)2 * D * w.in_proj.Kpad; g.lda0 = w.in_proj.Kpad; g.sA = 0;
+      g.Wt = ln; g.ldw = D; g.sW = (int64_t)T * D;
+      g.M = D; g.N = Tn; g.K = D; g.batch = B;
+      g.epi = EPI_BIAS_M; g.bias = w.in_proj.b + 2 * D;
+      g.C = vt; g.ldc = Tp; g.sC = (int64_t)D * Tp;
+      TSD_TRY(launch_gemm(ctx, g));
+    }
+    for (int b = 0; b < B; b++) {
+      GemmArgs s;  // scores[h] = q_h k_h^T / sqrt(64)   (helpers/attention.mojo:46,57-58)
+      s.A0 = qk + (int64_t)b * T * 2 * D; s.lda0 = 2 * D; s.sA = dh;
+      s.Wt = qk + (int64_t)b * T * 2 * D + D; s.ldw = 2 * D; s.sW = dh;
+      s.M = T; s.N = Tn; s.K = dh; s.batch = H;
+      s.out_scale = 0.125f;
+      s.C = sc; s.ldc = Tp; s.sC = (int64_t)T * Tp;
+      TSD_TRY(launch_gemm(ctx, s));
+      TSD_TRY(launch_softmax_rows_f16_causal(ctx, sc, (int64_t)H * T, T, Tp, T, Tp));
+      GemmArgs o;  // o_h = P_h v_h  (keys padded to 128 with zero probabilities / zero V^T columns)
+      o.A0 = sc; o.lda0 = Tp; o.sA = (int64_t)T * Tp;
+      o.Wt = vt + (int64_t)b * D * Tp; o.ldw = Tp; o.sW = (int64_t)dh * Tp;
+      o.M = T; o.N = dh; o.K = Tp; o.batch = H;
+      o.C = ao + (int64_t)b * T * D; o.ldc = D; o.sC = dh;
+      TSD_TRY(launch_gemm(ctx, o));
+    }
+    a.p0 = ao; a.ld0 = D; a.C0 = D;
+    TSD_TRY(g_linear(ctx, a, M, w.out_proj.w, w.out_proj.Kpad, D, D, w.out_proj.b, x, D, 0, x2, D));
+    // ---- LN -> Linear -> quick-GELU -> Linear -> + residue (clip.mojo:44-53) ----
+    TSD_TRY(launch_layernorm(ctx, x2, M, D, D, 1e-5f, ln, D));
+    a.p0 = ln;
+    TSD_TRY(g_linear(ctx, a, M, w.l4.w, w.l4.Kpad, 4 * D, D, w.l4.b, nullptr, 0, 0, ff, 4 * D));
+    TSD_TRY(launch_quick_gelu_f16(ctx, ff, M * 4 * D));
+    a.p0 = ff; a.ld0 = 4 * D; a.C0 = 4 * D;
+    TSD_TRY(g_linear(ctx, a, M, w.l5.w, w.l5.Kpad, D, 4 * D, w.l5.b, x2, D, 0, x, D));
+  }
+  TSD_TRY(launch_layernorm(ctx, x, M, D, D, 1e-5f, ln, D));  // clip.mojo:106-108
+  return launch_f16_to_f32_rows(ctx, ln, M, D, D, out_f32);
+}

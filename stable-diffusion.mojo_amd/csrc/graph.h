@@ -62,3 +62,5 @@ int run_planned(tsd_ctx* ctx, F&& fn) {
   a.top = 0;
   return r;
 }
+// tokens: device int32 [B][77]; out: device fp32 [B][77][768]
+int g_clip_forward(tsd_model* m, const int* tokens_dev, int B, float* out_f32);

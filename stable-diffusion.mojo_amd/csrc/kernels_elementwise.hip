@@ -177,14 +177,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// causal_period > 0: row r keeps columns <= r % causal_period (upper-triangle mask of helpers/attention.mojo:48-55,
+// intended form App.A D7); columns [kept, zero_to) are written as exact zeros (masked scores and K-padding of the
+// following P.V GEMM).
 template <class T>
 __global__ __launch_bounds__(256) void k_softmax_rows(const T* __restrict__ x, int cols, int ldx, T* __restrict__ y,
-                                                      int ldy) {
+                                                      int ldy, int causal_period, int zero_to) {
   __shared__ float red[8];
   const int64_t row = blockIdx.x;
   const T* xr = x + row * ldx;
   T* yr = y + row * ldy;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (causal_period > 0) cols = min(cols, (int)(row % causal_period) + 1);
+  for (int c = cols + tid; c < zero_to; c += 256) yr[c] = (T)0.f;
   float m = -3.0e38f;
   for (int c = tid; c < cols; c += 256) m = fmaxf(m, (float)xr[c]);
   m = wave_max(m);
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const T* __restrict__ x, i
 }
 int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols, float* y) {
   if (!ctx->launch()) return TSD_OK;
-  hipLaunchKernelGGL(k_softmax_rows<float>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, x, cols, cols, y, cols);
+  hipLaunchKernelGGL(k_softmax_rows<float>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, x, cols, cols, y, cols, 0, 0);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -210,7 +215,64 @@ int launch_softmax_rows_f16(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_SOFTMAX);
   hipLaunchKernelGGL(k_softmax_rows<half_t>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const half_t*)x, cols,
-                     ld, x, ld);
+                     ld, x, ld, 0, 0);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+int launch_softmax_rows_f16_causal(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld, int period, int zero_to) {
+  if (period <= 0 || zero_to > ld) TSD_FAIL(TSD_E_ARG, "causal softmax: bad period / padding");
+  if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_SOFTMAX);
+  hipLaunchKernelGGL(k_softmax_rows<half_t>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const half_t*)x, cols,
+                     ld, x, ld, period, zero_to);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- CLIP: token + position embedding (clip.mojo:17-20, helpers/utils.mojo:2032-2046 intended form App.A D3) ----
+__global__ __launch_bounds__(128) void k_clip_embed(const int* __restrict__ tokens, const half_t* __restrict__ table,
+                                                    int n_vocab, int D, const float* __restrict__ pos, int T,
+                                                    half_t* __restrict__ y) {
+  const int64_t row = blockIdx.x;  // b * T + t
+  int tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= n_vocab ? n_vocab - 1 : tok);  // index clamp like Matrix.__getitem__ (helpers/utils.mojo:770-777)
+  const half_t* e = table + (int64_t)tok * D;
+  const float* pr = pos + (int64_t)(row % T) * D;
+  for (int c = threadIdx.x * 8; c < D; c += 128 * 8) {
+    const h8 v = *(const h8*)(e + c);
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (half_t)((float)v[j] + pr[c + j]);
+    *(h8*)(y + row * D + c) = o;
+  }
+}
+int launch_clip_embed(tsd_ctx* ctx, const int* tokens, const half_t* table, int n_vocab, int D, const float* pos, int B,
+                      int T, half_t* y) {
+  if (D % 8) TSD_FAIL(TSD_E_SHAPE, "clip embedding: D=%d", D);
+  if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
+  hipLaunchKernelGGL(k_clip_embed, dim3(B * T), dim3(128), 0, ctx->stream, tokens, table, n_vocab, D, pos, T, y);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- CLIP: quick-GELU x * sigmoid(1.702 x) in place on fp16 (clip.mojo:49-50, intended form App.A D15) ----
+__global__ __launch_bounds__(256) void k_quick_gelu_f16(half_t* __restrict__ x, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  h8 v = *(const h8*)(x + i * 8);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const float f = (float)v[j];
+    v[j] = (half_t)(f / (1.f + __expf(-1.702f * f)));
+  }
+  *(h8*)(x + i * 8) = v;
+}
+int launch_quick_gelu_f16(tsd_ctx* ctx, half_t* x, int64_t n) {
+  if (n % 8) TSD_FAIL(TSD_E_SHAPE, "quick_gelu: n must be a multiple of 8");
+  if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
+  hipLaunchKernelGGL(k_quick_gelu_f16, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, ctx->stream, x, n / 8);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

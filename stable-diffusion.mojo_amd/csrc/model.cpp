@@ -16,7 +16,7 @@ static size_t packed_bytes(const ParamSpec& p) {
 
 extern "C" int tsd_model_create(tsd_ctx* ctx, int kind, tsd_model** out) {
   if (!ctx || !out) TSD_FAIL(TSD_E_ARG, "tsd_model_create: NULL argument");
-  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_ENCODER) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_CLIP) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
   tsd_model* m = new tsd_model();
   m->ctx = ctx;
   m->kind = kind;
@@ -211,6 +211,17 @@ int model_resolve(tsd_model* m) {
     u.conv4 = model_conv(m, "unet.layer4");
     u.conv7 = model_conv(m, "unet.layer7");
     u.final_conv = model_conv(m, "final.layer2");
+  } else if (m->kind == TSD_MODEL_CLIP) {
+    ClipW& c = m->clip;
+    c.tok = (const half_t*)(m->blob + m->params[m->index.at("embedding.token.weight")].off);
+    c.pos = (const float*)(m->blob + m->params[m->index.at("embedding.position")].off);
+    for (int i = 0; i < 12; i++) {
+      const std::string n = "player" + std::to_string(i + 1);
+      c.layer[i].in_proj = model_lin(m, n + ".layer2.in_proj", true);
+      c.layer[i].out_proj = model_lin(m, n + ".layer2.out_proj", true);
+      c.layer[i].l4 = model_lin(m, n + ".layer4", true);
+      c.layer[i].l5 = model_lin(m, n + ".layer5", true);
+    }
   } else {
     const LayerDef* L = m->kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
     const int n_layers = m->kind == TSD_MODEL_DECODER ? 26 : 19;

@@ -68,6 +68,13 @@ struct VaeW {
   std::vector<VaeAttnW> attn;
 };
 
+struct ClipLayerW { LinW in_proj, out_proj, l4, l5; };  // ClipPlayer clip.mojo:23-34 (its LayerNorms have no parameters)
+struct ClipW {
+  const half_t* tok = nullptr;  // [49408][768] fp16
+  const float* pos = nullptr;   // [77][768] fp32
+  ClipLayerW layer[12];
+};
+
 struct PlanKey { int B, L, T; bool operator<(const PlanKey& o) const { return B != o.B ? B < o.B : (L != o.L ? L < o.L : T < o.T); } };
 
 struct tsd_model {
@@ -81,6 +88,7 @@ struct tsd_model {
   bool ready = false;
   UNetW unet;
   VaeW vae;
+  ClipW clip;
   std::map<PlanKey, size_t> plans;  // workspace high-water mark per problem shape
 };
 

@@ -102,6 +102,22 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       else if (l.kind == L_ATTN) b.unet_attn(n, l.a, l.b);
     }
     b.conv("final.layer2", 320, 4, 3, true, true);
+  } else if (kind == TSD_MODEL_CLIP) {  // clip.mojo:74-88 ; parameter order = oracle/spec.py clip_params()
+    ParamSpec t;
+    t.name = "embedding.token.weight"; t.ndim = 2; t.shape[0] = 49408; t.shape[1] = 768; t.kind = P_LIN_W;
+    t.bound = 1.7320508075688772f;  // unit variance like init_weights_normal(0,1), helpers/utils.mojo:2025
+    t.Kpad = 768; t.Opad = 49408;
+    b.out.push_back(t);
+    ParamSpec p;
+    p.name = "embedding.position"; p.ndim = 1; p.shape[0] = 77 * 768; p.kind = P_LIN_B; p.bound = 0.02f; p.Opad = 77 * 768;
+    b.out.push_back(p);
+    for (int i = 1; i <= 12; i++) {
+      const std::string n = "player" + std::to_string(i);
+      b.lin(n + ".layer2.in_proj", 768, 3 * 768);
+      b.lin(n + ".layer2.out_proj", 768, 768);
+      b.lin(n + ".layer4", 768, 4 * 768);
+      b.lin(n + ".layer5", 4 * 768, 768);
+    }
   } else if (kind == TSD_MODEL_DECODER || kind == TSD_MODEL_ENCODER) {
     const LayerDef* L = kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
     const int n_layers = kind == TSD_MODEL_DECODER ? 26 : 19;
@@ -117,13 +133,13 @@ std::vector<ParamSpec> build_param_specs(int kind) {
 }
 
 extern "C" int tsd_model_param_count(int kind) {
-  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_ENCODER) return TSD_E_ARG;
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_CLIP) return TSD_E_ARG;
   return (int)build_param_specs(kind).size();
 }
 
 extern "C" int tsd_model_param_info(int kind, int index, char* name, int name_cap, int64_t shape[4], int* ndim,
                                     int* used, float* init_bound) {
-  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_ENCODER) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_CLIP) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
   static thread_local int cached_kind = 0;
   static thread_local std::vector<ParamSpec> cached;
   if (cached_kind != kind) {
@@ -191,6 +207,9 @@ extern "C" double tsd_flop_count(int kind, int L, int T) {
       else if (l.kind == L_ATTN) f += vae_attn_f(l.a, side * side);
       else if (l.kind == L_UP) side *= 2;
     }
+  } else if (kind == TSD_MODEL_CLIP) {  // per prompt: 12 x (in_proj, QK^T, PV, out_proj, 768->3072->768) on 77 tokens
+    const double Tc = 77, D = 768;
+    f = 12.0 * (lin_f(Tc, D, 3 * D) + 2.0 * 2.0 * Tc * Tc * D + lin_f(Tc, D, D) + lin_f(Tc, D, 4 * D) + lin_f(Tc, 4 * D, D));
   } else {
     return -1.0;
   }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtsd.so")
 
 TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE = 0, -1, -2, -3, -4, -5, -6
-MODEL_DIFFUSION, MODEL_DECODER, MODEL_ENCODER = 1, 2, 3
+MODEL_DIFFUSION, MODEL_DECODER, MODEL_ENCODER, MODEL_CLIP = 1, 2, 3, 4
 
 
 class TsdError(RuntimeError):
@@ -80,6 +80,7 @@ def _declare(l):
         "tsd_diffusion_forward": ([vp, fp, fp, fp, i, i, i, fp], i),
         "tsd_decoder_forward": ([vp, fp, i, i, fp], i),
         "tsd_encoder_forward": ([vp, fp, fp, i, i, fp], i),
+        "tsd_clip_forward": ([vp, C.POINTER(C.c_int32), i, i, fp], i),
         "tsd_session_create": ([vp, vp, i, i, i, i, pp], i), "tsd_session_destroy": ([vp], i),
         "tsd_session_set_schedule": ([vp, i, i, i], i), "tsd_session_num_steps": ([vp], i),
         "tsd_session_timestep": ([vp, i], i),

@@ -6,7 +6,8 @@ import numpy as np
 from . import _lib
 from ._lib import check, f32, lib, ptr, vp
 
-KINDS = {"diffusion": _lib.MODEL_DIFFUSION, "decoder": _lib.MODEL_DECODER, "encoder": _lib.MODEL_ENCODER}
+KINDS = {"diffusion": _lib.MODEL_DIFFUSION, "decoder": _lib.MODEL_DECODER, "encoder": _lib.MODEL_ENCODER,
+         "clip": _lib.MODEL_CLIP}
 
 
 def param_specs(kind):

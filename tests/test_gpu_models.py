@@ -264,3 +264,23 @@ def test_conv_linearity_at_full_size(gpu_ctx, tsd_mod):
     lhs = c.forward(x + y)
     rhs = c.forward(x) + c.forward(y)
     assert rel_l2(lhs, rhs) < 2e-3
+
+
+def test_clip_forward_matches_oracle(gpu_ctx, tsd_mod):
+    """CLIP text encoder: token ids -> (77, 768) context, two prompts of different length in
+    one batch, device-initialised weights == oracle RNG weights; plus the padding / causality properties."""
+    P = spec.init_params("clip", SEED)
+    clip = tsd_mod.CLIP(seed=SEED)
+    toks = np.zeros((2, 9), dtype=np.int32)
+    toks[0, :9] = [49406, 320, 1125, 539, 320, 2368, 4558, 267, 49407]
+    toks[1, :4] = [49406, 1237, 7, 49407]
+    out = clip.forward(toks)
+    ref = np.stack([models.clip(P, toks[0]), models.clip(P, toks[1])])
+    assert_close(out, ref, TOL_MODEL, None, "CLIP.forward (2 prompts)")
+    one = clip.forward(toks[1, :4])
+    assert one.shape == (77, 768)
+    np.testing.assert_array_equal(one, out[1])                  # batch-invariant, zero padding == explicit zeros
+    longer = clip.forward(np.concatenate([toks[1, :4], [99, 98, 97]]).astype(np.int32))
+    np.testing.assert_array_equal(longer[:4], one[:4])          # causal mask: earlier rows ignore later tokens
+    assert not np.array_equal(longer[4:7], one[4:7])
+    clip.model.close()

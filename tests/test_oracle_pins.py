@@ -176,3 +176,39 @@ def test_cfg_combine_and_rescale():
     np.testing.assert_allclose(sampler.cfg_combine(c, u, 7.5), (c - u) * 7.5 + u, rtol=1e-6)
     np.testing.assert_allclose(ops.rescale_to_u8_range(np.array([-2.0, -1.0, 0.0, 1.0, 3.0], dtype=np.float32)),
                                [0.0, 0.0, 127.5, 255.0, 255.0])
+
+
+def test_clip_pieces_match_torch():
+    """CLIP: quick-GELU, the causal mask, the embedding gather and one ClipPlayer layer
+    against torch restatements of the intended semantics (App.A D3 / D7 / D15)."""
+    x = randn(40, 5, 33)
+    np.testing.assert_allclose(ops.quick_gelu(x), (T(x) * torch.sigmoid(1.702 * T(x))).numpy(), rtol=1e-5, atol=1e-6)
+    table = randn(41, 11, 8)
+    np.testing.assert_array_equal(ops.embedding([3, 0, 10, 3], table), table[[3, 0, 10, 3]])
+    # causal self-attention: F.scaled_dot_product_attention(is_causal=True)
+    t, wi, bi, wo, bo = randn(42, 9, 24), randn(43, 72, 24) * 0.2, randn(44, 72) * 0.1, randn(45, 24, 24) * 0.2, randn(46, 24)
+    y = ops.self_attention(t, 3, wi, bi, wo, bo, causal=True)
+    qkv = T(t) @ T(wi).T + T(bi)
+    q, k, v = qkv.chunk(3, -1)
+    sh = lambda a: a.view(9, 3, 8).transpose(0, 1)[None]  # noqa: E731
+    o = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), is_causal=True)[0].transpose(0, 1).reshape(9, 24)
+    np.testing.assert_allclose(y, (o @ T(wo).T + T(bo)).numpy(), rtol=1e-4, atol=1e-5)
+    # first token attends only to itself: its output is out_proj(v_0)
+    np.testing.assert_allclose(y[0], (v[0] @ T(wo).T + T(bo)).numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_clip_parameter_census_and_padding():
+    n = sum(p.numel for p in spec.clip_params())
+    assert n == 49408 * 768 + 77 * 768 + 12 * (3 * 768 * 768 + 3 * 768 + 768 * 768 + 768 + 2 * 4 * 768 * 768 + 4 * 768 + 768)
+    P = {p.name: (randn(hash(p.name) % 997 + 200, *p.shape) * 0.05).astype(np.float32) for p in spec.clip_params()
+         if not p.name.startswith("embedding.token")}
+    P["embedding.token.weight"] = randn(47, 64, 768)[np.arange(49408) % 64]  # small table tiled to the vocabulary size
+    a = models.clip(P, [5, 9, 2])
+    b = models.clip(P, [5, 9, 2] + [0] * 74)  # prompts are zero-padded to 77 ids (clip.mojo:91-93)
+    assert a.shape == (77, 768)
+    np.testing.assert_array_equal(a, b)
+    # causal: the first three output rows do not depend on later tokens
+    c = models.clip(P, [5, 9, 2, 40, 41])
+    np.testing.assert_allclose(a[:3], c[:3], rtol=1e-5, atol=1e-6)
+    # per-token LayerNorm with no affine at the end: zero mean over channels
+    np.testing.assert_allclose(a.mean(axis=-1), 0.0, atol=1e-4)
