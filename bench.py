@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=77)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the VAE-decode timing used for images/s")
+    ap.add_argument("--cfg", action="store_true",
+                    help="also time the loop with classifier-free guidance (UNet batch 2B per step) as an extra field")
     ap.add_argument("--img2img", action="store_true",
                     help="also time the VAE encoder and report BASELINE configs[3] (encoder + 30 steps + decoder) as an extra field")
     args = ap.parse_args()
@@ -224,6 +226,21 @@ def main():
             dec_ms = ctx.timer_stop()
         ms_per_step = 1e3 * dt / K
         steps_per_s = world * K / dt
+        # ---- classifier-free guidance: conditional + unconditional pass batched (2B samples per UNet call) ----
+        cfg_ms = None
+        if args.cfg:
+            un = np.stack([tsd.rng.normal(SEED, 4000 + i, T * 768).reshape(T, 768) for i in range(lo, hi)])
+            s2 = tsd.Session(unet.model, None, B, L, T, cfg=True)
+            s2.set_schedule(1000, n_sched, 0)
+            s2.upload(lat, cx, un, noise, 7.5)
+            for i in range(2):
+                s2.step(i)
+            ctx.synchronize()
+            ctx.timer_start()
+            for i in range(K):
+                s2.step((2 + i) % n_sched)
+            cfg_ms = ctx.timer_stop() / K
+            s2.close()
         # ---- BASELINE configs[3] (img2img): VAE encoder on B x (3,512,512) + strength 0.6 of the schedule + decoder ----
         enc_ms = None
         if args.img2img and dec is not None:
@@ -251,6 +268,7 @@ def main():
                                    f"{T}-token context, no CFG, random-init weights (BASELINE configs[1])",
                        "global_batch": world * B, "parallelism": f"dp{world} (independent prompts, weights broadcast once)"},
             "images_per_s_end_to_end": round(images_per_s, 4), "decode_ms": None if dec_ms is None else round(dec_ms, 3),
+            "cfg_ms_per_step": None if cfg_ms is None else round(cfg_ms, 4),
             "img2img_config4": None if enc_ms is None else {
                 "encode_ms_host_boundary": round(enc_ms, 3), "steps": int(n_sched * 0.6),
                 "images_per_s": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
