@@ -197,6 +197,20 @@ int tsd_encoder_forward(tsd_model* m, const float* images, const float* noise, i
  * Token embedding + learned position table, 12 x (LayerNorm, causal 12-head self-attention, +res, LayerNorm,
  * Linear 768->3072, quick-GELU x*sigmoid(1.702x), Linear 3072->768, +res), final LayerNorm. */
 int tsd_clip_forward(tsd_model* m, const int32_t* tokens, int B, int T, float* context);
+
+/* ---- prompt tokenizer (host only, no GPU): `Tokenizer` + `bpe_encode`, helpers/utils.mojo:229-327, over the
+ * tokenizer_clip.bin wire format of tokenizer_creation.py:43-48 (u32 max_token_length; per token f32 score, u32 length,
+ * bytes).  pipeline.mojo:37-51: Tokenizer(49408, buf); ids = bpe_encode(prompt.replace(" ", "</w>"), tokenizer). ---- */
+typedef struct tsd_tokenizer tsd_tokenizer;
+int tsd_tokenizer_create(const char* path, int vocab_size, tsd_tokenizer** out);
+int tsd_tokenizer_create_from_memory(const void* data, size_t bytes, int vocab_size, tsd_tokenizer** out);
+int tsd_tokenizer_destroy(tsd_tokenizer* t);
+/* `Tokenizer.find` :270-287 (with `wrap` :200-209): id of `token`, -1 when absent. */
+int tsd_tokenizer_find(const tsd_tokenizer* t, const char* token);
+/* vocabulary entry `id` -> bytes (NUL-terminated, truncated to cap) and score */
+int tsd_tokenizer_token(const tsd_tokenizer* t, int id, char* out, int cap, float* score);
+/* `bpe_encode` :289-327. ids may be NULL to query the count; *complete = 0 when an unknown character ended it early. */
+int tsd_tokenizer_encode(const tsd_tokenizer* t, const char* text, int32_t* ids, int cap, int* n_out, int* complete);
 /* pipeline.mojo:127 `rescale((-1,1),(0,255),clamp=True)` (helpers/utils.mojo:577-597). */
 int tsd_rescale_images_f32(tsd_ctx* ctx, const float* x, int64_t n, float* y);
 

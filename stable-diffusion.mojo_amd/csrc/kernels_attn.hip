@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   };
 
   // constant part of both V^T buffers: rows D..VROWS (zero; row D = ones when it carries the row sums)
+  constexpr int PADCH = (VROWS - D) * 8 > 0 ? (VROWS - D) * 8 : 1;  // 16-B chunks of constant rows per buffer (0 at d = 160)
   for (int i = tid; i < NST * (VROWS - D) * 8; i += 256) {
-    const int buf = i / ((VROWS - D) * 8), rem = i - buf * (VROWS - D) * 8;
+    const int buf = i / PADCH, rem = i - buf * PADCH;
     const int R = D + (rem >> 3), pos = rem & 7;
     const half_t fill = (ONES_ROW && R == D) ? (half_t)1.f : (half_t)0.f;
     *(h8*)(smem + buf * BUF_BYTES + K_BYTES + R * 128 + pos * 16) = h8{fill, fill, fill, fill, fill, fill, fill, fill};

@@ -5,7 +5,8 @@
   tsd.diffusion  <-> diffusion.mojo         Time_Embedding, Unet_Residual_Block, Unet_Attention_Block, UNet, Diffusion
   tsd.vae        <-> vae.mojo               Attention_Block, Res_Block, Decoder, Encoder
   tsd.sampler    <-> sampler.mojo           DDPMSampler
-  tsd.clip       <-> clip.mojo              CLIP text encoder (token ids -> context; the tokenizer is out of scope)
+  tsd.clip       <-> clip.mojo              CLIP text encoder (token ids -> context)
+  tsd.tokenizer  <-> helpers/utils.mojo     Tokenizer, bpe_encode (host-only logic inside libtsd)
   tsd.pipeline   <-> pipeline.mojo          generate (hot loop; the context embedding is an input)
 
 Every forward() is a call through the C ABI in include/tsd.h into hand-written HIP kernels for gfx950.
@@ -21,5 +22,6 @@ from .diffusion import (Diffusion, Time_Embedding, UNet, UNet_Output_Layer, Unet
                         Unet_Residual_Block)
 from .vae import Attention_Block, Decoder, Encoder, Res_Block  # noqa: F401
 from .clip import CLIP  # noqa: F401
+from .tokenizer import Tokenizer, process_prompt  # noqa: F401
 from .sampler import DDPMSampler  # noqa: F401
-from .pipeline import generate  # noqa: F401
+from .pipeline import encode_prompts, generate  # noqa: F401

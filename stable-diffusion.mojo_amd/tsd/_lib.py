@@ -81,6 +81,12 @@ def _declare(l):
         "tsd_decoder_forward": ([vp, fp, i, i, fp], i),
         "tsd_encoder_forward": ([vp, fp, fp, i, i, fp], i),
         "tsd_clip_forward": ([vp, C.POINTER(C.c_int32), i, i, fp], i),
+        "tsd_tokenizer_create": ([C.c_char_p, i, C.POINTER(vp)], i),
+        "tsd_tokenizer_create_from_memory": ([C.c_char_p, C.c_size_t, i, C.POINTER(vp)], i),
+        "tsd_tokenizer_destroy": ([vp], i),
+        "tsd_tokenizer_find": ([vp, C.c_char_p], i),
+        "tsd_tokenizer_token": ([vp, i, C.c_char_p, i, fp], i),
+        "tsd_tokenizer_encode": ([vp, C.c_char_p, C.POINTER(C.c_int32), i, C.POINTER(C.c_int), C.POINTER(C.c_int)], i),
         "tsd_session_create": ([vp, vp, i, i, i, i, pp], i), "tsd_session_destroy": ([vp], i),
         "tsd_session_set_schedule": ([vp, i, i, i], i), "tsd_session_num_steps": ([vp], i),
         "tsd_session_timestep": ([vp, i], i),

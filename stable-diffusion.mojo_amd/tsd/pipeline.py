@@ -1,12 +1,25 @@
-"""Host-side mirror of the hot part of `pipeline.generate` (pipeline.mojo:57-127): sampler -> [encoder] ->
-denoise loop (UNet x1 or x2 with CFG) -> decoder -> rescale.  CLIP and the tokenizer are out of scope
-(SURVEY.md section 2 rows 9-11): the context embedding is an input.  Batched over independent prompts
-(the reference is batch 1; `pipeline.mojo:12` suggests exactly this batching)."""
+"""Host-side mirror of `pipeline.generate` (pipeline.mojo:12-127): [tokenizer -> CLIP ->] sampler -> [encoder] ->
+denoise loop (UNet x1 or x2 with CFG) -> decoder -> rescale.  The context embedding is normally an input (the
+measured path starts there); `encode_prompts` is the reference's prompt front end (pipeline.mojo:31-54).  Batched
+over independent prompts (the reference is batch 1; `pipeline.mojo:12` suggests exactly this batching)."""
 import numpy as np
 
 from . import rng
 from .model import Session
 from .utils import rescale
+
+
+def encode_prompts(prompts, tokenizer, clip):
+    """pipeline.mojo:39-54: ids = bpe_encode(prompt.replace(" ", "</w>")) -> CLIP.forward -> (B, 77, 768).
+    Prompts longer than 77 ids are cut to 77 (the reference's `set_items` into a 77-wide row, clip.mojo:91-93)."""
+    from .tokenizer import process_prompt
+    if isinstance(prompts, str):
+        prompts = [prompts]
+    ids = np.zeros((len(prompts), 77), dtype=np.int32)
+    for i, p in enumerate(prompts):
+        t = tokenizer.bpe_encode(process_prompt(p))[:77]
+        ids[i, : len(t)] = t
+    return clip.forward(ids)
 
 
 def generate(diffusion, decoder, context, uncond_context=None, strength=0.8, cfg=True, cfg_scale=7.5,
