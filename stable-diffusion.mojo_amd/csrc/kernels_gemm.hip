@@ -783,18 +783,22 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   const int Hi = ups ? 2 * H : H, Wi = ups ? 2 * W : W;
   const int Ho = conv ? (Hi + 2 - 3) / stride + 1 : H, Wo = conv ? (Wi + 2 - 3) / stride + 1 : W;
   const int64_t M = (int64_t)B * Ho * Wo, K = conv ? 9 * (int64_t)Cin : Cin;
-  const int64_t na = (int64_t)B * H * W * Cin, nw = (int64_t)N * K, nc = M * N;
-  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + 2 * nc) * 2 + (size_t)std::max(na, nw) * 4 + (size_t)N * 4 + 8192));
+  // TSD_BENCH_WROT=R: R copies of the weights used round-robin, so each launch streams cold weights like a real step
+  const int wrot = getenv("TSD_BENCH_WROT") ? std::max(1, atoi(getenv("TSD_BENCH_WROT"))) : 1;
+  const int64_t na = (int64_t)B * H * W * Cin, nw1 = (int64_t)N * K, nw = nw1 * wrot, nc = M * N;
+  TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + 2 * nc) * 2 + (size_t)std::max(na, nw1) * 4 + (size_t)N * 4 + 8192));
   ctx->arena.top = 0;
   half_t* A = arena_alloc<half_t>(ctx, na);
   half_t* Wt = arena_alloc<half_t>(ctx, nw);
   half_t* C = arena_alloc<half_t>(ctx, nc);
-  float* tmp = arena_alloc<float>(ctx, std::max(na, nw));
+  float* tmp = arena_alloc<float>(ctx, std::max(na, nw1));
   if (!A || !Wt || !C || !tmp) TSD_FAIL(TSD_E_ALLOC, "gemm_bench: arena");
   TSD_TRY(launch_fill_uniform(ctx, tmp, na, 1, 1, 1.f));
   TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)std::min<int64_t>(na, 1 << 30), A, (int)std::min<int64_t>(na, 1 << 30), 1));
-  TSD_TRY(launch_fill_uniform(ctx, tmp, nw, 1, 2, 0.05f));
-  TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nw, Wt, (int)nw, 1));
+  for (int r = 0; r < wrot; r++) {
+    TSD_TRY(launch_fill_uniform(ctx, tmp, nw1, 1, 2, 0.05f));
+    TSD_TRY(launch_f32_to_f16_rows(ctx, tmp, 1, (int)nw1, Wt + r * nw1, (int)nw1, 1));
+  }
   GemmArgs g;
   g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.C = C; g.ldc = N;
   if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
@@ -849,6 +853,7 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   const int alt = getenv("TSD_BENCH_ALTCFG") ? atoi(getenv("TSD_BENCH_ALTCFG")) : -1;  // alternate two kernels (cold I-cache probe)
   for (int i = 0; i < iters && r == TSD_OK; i++) {
     if (alt >= 0) g_force_cfg = (i & 1) ? alt : cfg;
+    g.Wt = Wt + (int64_t)(i % wrot) * nw1;
     r = launch_gemm(ctx, g);
   }
   g_force_cfg = -1;
