@@ -248,6 +248,10 @@ int tsd_dist_finalize(tsd_ctx* ctx);
 /* ---- debug / tuning -------------------------------------------------------------------- */
 /* Time one GEMM (conv = 0: M = B*H*W, K = Cin) or conv3x3 problem on synthetic device data with tile
  * configuration `cfg` (< 0: dispatcher's choice); average ms per launch over `iters` launches. */
+/* split-K hand-offs that timed out or paired blocks on different XCDs since the context was created (must be 0);
+ * 1 when workgroups map to XCDs round-robin (the precondition of the L2-local split-K hand-off). */
+int tsd_debug_splitk_errors(tsd_ctx* ctx);
+int tsd_debug_xcd_round_robin(void);
 int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
                          int iters, float* ms);
 

@@ -166,6 +166,8 @@ struct GemmArgs {
   float out_scale = 1.f;  // applied to the accumulator before bias/residual
   // EPI_GNSTATS: partial[(b * gn_nslab + slab) * gn_groups + g][2], slab = wave-tile row block within the sample
   float* gn_part = nullptr; int gn_groups = 0, gn_rows_per_sample = 0, gn_nslab = 0;
+  // rows of one sample (H*W) when the caller knows it: lets few-row, long-K layers run split-K independently of the batch
+  int rows_per_sample_hint = 0;
 };
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a);
 int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups);  // 0: not available

@@ -52,6 +52,7 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
   if (res) { g.epi |= EPI_RESIDUAL | (res_ups ? EPI_RES_UPS : 0); g.R = res->p; g.ldr = res->ld; }
   if (out_f32) g.epi |= EPI_OUT_F32;
   g.C = y; g.ldc = ldy;
+  g.rows_per_sample_hint = Ho * Wo;
   gn_emit(g, stat, Ho * Wo);
   return launch_gemm(ctx, g);
 }
@@ -66,6 +67,7 @@ int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw,
   if (bias) { g.epi |= EPI_BIAS_N; g.bias = bias; }
   if (res) { g.epi |= EPI_RESIDUAL; g.R = res; g.ldr = ldr; }
   g.C = y; g.ldc = ldy;
+  g.rows_per_sample_hint = rows_per_sample;
   gn_emit(g, stat, rows_per_sample);
   return launch_gemm(ctx, g);
 }
@@ -194,7 +196,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C));
   half_t* tok4 = tok2;  // tok2 is dead after tok3
   CatSrc ag; ag.p0 = gg; ag.ld0 = 4 * C; ag.C0 = 4 * C;
-  TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C));
+  TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C, nullptr, S));
   // ---- output 1x1 conv + long residual (:146) ----
   a.p0 = tok4;
   TSD_TRY(g_linear(ctx, a, M, w.conv_out.w, w.conv_out.Ipad, C, C, w.conv_out.b, x.p, x.ld, 0, out.p, out.ld, &out, S));

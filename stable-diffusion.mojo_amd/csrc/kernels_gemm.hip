@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "common.h"
@@ -51,6 +52,7 @@ struct GemmK {
   int epi, tiles_n, xcd_n;
   float out_scale;
   float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
+  float* sk_ws; int* sk_flags; int splitk;             // split-K (2): fp32 partial tiles + one arrival flag per tile
 #ifdef TSD_GEMM_TS
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
 #endif
@@ -101,22 +103,30 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // tile columns, so through its private L2 it pulls 1/xcd_n of W and xcd_n/8 of A.  The host picks xcd_n to minimise
   // the fabric traffic W_bytes * (8/xcd_n) + A_bytes * xcd_n (weight-heavy M = 2048 problems want xcd_n = 8: with
   // row-only ownership every XCD re-fetched the whole 29 MB conv weight).  xcd_n = 1 is the row-only bijective remap.
-  int bid = blockIdx.x;
+  // Split-K (p.splitk == 2, few-tile problems with a long K): the grid holds every tile twice.  The first `ntile`
+  // blocks take the SECOND half of K and hand their fp32 partial tile to the block `ntile` ids later (same XCD, so
+  // the same L2), which takes the first half, adds the partial in a fixed order and runs the epilogue.
+  const int ntile = p.splitk > 1 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const int ks = p.splitk > 1 ? (blockIdx.x >= (unsigned)ntile ? 0 : 1) : 0;
+  int bid = p.splitk > 1 && ks == 0 ? (int)blockIdx.x - ntile : (int)blockIdx.x;
   int tm, tn;
   if (p.xcd_n > 1) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int xi = xcd / p.xcd_n, xj = xcd - xi * p.xcd_n;
-    const int tnx = p.tiles_n / p.xcd_n, tmx = (gridDim.x / p.tiles_n) / (8 / p.xcd_n);
+    const int tnx = p.tiles_n / p.xcd_n, tmx = (ntile / p.tiles_n) / (8 / p.xcd_n);
     const int ltm = idx / tnx, ltn = idx - ltm * tnx;
     tm = xi * tmx + ltm;
     tn = xj * tnx + ltn;
   } else {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int nwg = ntile, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     tm = bid / p.tiles_n;
     tn = bid - tm * p.tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  const int nk_all = p.K >> 6;
+  const int kt0 = ks ? nk_all >> 1 : 0;                                   // first K-tile of this block
+  const int nk = p.splitk > 1 ? (ks ? nk_all - (nk_all >> 1) : nk_all >> 1) : nk_all;  // and how many it owns
   const int bz = blockIdx.y;
   const half_t* A0 = p.A0 + (long long)bz * p.sA;
   const half_t* A1 = p.A1 ? p.A1 + (long long)bz * p.sA : nullptr;
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 
   // conv: running (tap, channel-chunk) of the NEXT tile to stage
   const int cpt = CONV ? (p.Cin >> 6) : 1;
-  int st_tap = 0, st_cc = 0;
+  int st_tap = kt0 / cpt, st_cc = kt0 - (kt0 / cpt) * cpt;
   auto conv_tap_ptrs = [&](int tap) {
     const int kh = tap / 3, kw = tap - kh * 3;
     const int Heff = p.ups ? 2 * p.Hs : p.Hs, Weff = p.ups ? 2 * p.Ws : p.Ws;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + sy) * p.Ws + sx) * (unsigned)p.lda0 + cch * 8) * 2 : PAD_OFF;
     }
   };
-  if constexpr (CONV) conv_tap_ptrs(0);
+  if constexpr (CONV) conv_tap_ptrs(st_tap);
 
   // One K-tile = A_PW + W_PW DMA instructions per wave.  A TileSrc holds the wave-uniform part of their addresses;
   // stage_piece() issues the i-th instruction so the pinned schedule can drop them one at a time into the shadow of
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   auto tile_src = [&](int kt, bool live) {
     TileSrc t;
     const int nrec = live ? 0x7ffffff0 : 0;
-    const int k0 = kt * 64;
+    const int k0 = (kt0 + kt) * 64;
     t.second = !CONV && k0 >= p.K0;  // wave-uniform: second concat source
     if constexpr (CONV) {
       t.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(A0), 0, nrec, 0x00020000);
@@ -288,7 +298,6 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     }
   };
 
-  const int nk = p.K >> 6;
   // DMA instructions per stage per wave: waves below the remainder issue one more (wave-uniform)
   constexpr int LPS_HI = A_PW + W_PW;
   constexpr int LPS_LO = (A_INSTR % NW ? A_PW - 1 : A_PW) + (W_INSTR % NW ? W_PW - 1 : W_PW);
@@ -391,6 +400,54 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   }
 
   TS_MARK(2);
+  // ---- split-K hand-off ---------------------------------------------------------------------
+  if (p.splitk > 1) {
+    // partial tile in the accumulator layout: (fragment, lane) -> 16 B, so every wave instruction moves 1 KiB contiguous
+    float* wsw = p.sk_ws + ((long long)(tm * p.tiles_n + tn) * NW + wave) * (FM * FN * 256);
+    int* flag = p.sk_flags + tm * p.tiles_n + tn;
+    if (ks) {  // producer: second half of K
+      wait_vmcnt<0>();  // dead tail DMA has landed before the wave may end
+#pragma unroll
+      for (int a = 0; a < FM; a++)
+#pragma unroll
+        for (int b = 0; b < FN; b++) *(f4*)(wsw + ((a * FN + b) * 64 + lane) * 4) = acc[a][b];
+#ifdef TSD_SPLITK_AGENT_FENCE
+      __threadfence();  // partial visible device-wide before the flag
+#else
+      wait_vmcnt<0>();  // stores acknowledged by the XCD's L2, which the partner block (same XCD) reads from
+#endif
+      __syncthreads();
+      if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store(flag, 1 + (int)(xcc & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    if (tid == 0) {  // consumer: bounded wait for the partner (all 2*ntile blocks are co-resident: ntile*2 <= CU count)
+      int spins = 0;
+      int f;
+      while ((f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(4);
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      if (f == 0 || f - 1 != (int)(xcc & 0xf)) atomicAdd(&p.sk_flags[4095], 1);  // timeout, or the pair is split across XCDs:
+                                                                                 // tsd_debug_splitk_errors() reports it
+    }
+    __syncthreads();
+#ifdef TSD_SPLITK_AGENT_FENCE
+    __threadfence();
+#else
+    asm volatile("" ::: "memory");  // this CU's L1 holds no line of the workspace yet (invalidated at kernel start): the loads go to L2
+#endif
+#pragma unroll
+    for (int a = 0; a < FM; a++)
+#pragma unroll
+      for (int b = 0; b < FN; b++) {
+        const f4 v = __builtin_nontemporal_load((const f4*)(wsw + ((a * FN + b) * 64 + lane) * 4));
+        acc[a][b] += v;  // fixed order: first half + second half
+      }
+    if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  }
   // ---- epilogue ---------------------------------------------------------------------------
   const int g = lane >> 4;
   const int epi = p.epi;
@@ -669,7 +726,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
     if (force > 0) best = (kk.tiles_n % force == 0 && tiles_m % (8 / force) == 0) ? force : 1;
     kk.xcd_n = best;
   }
-  dim3 grid(tiles_m * kk.tiles_n, batch);
+  dim3 grid(tiles_m * kk.tiles_n * (kk.splitk > 1 ? 2 : 1), batch);
   hipLaunchKernelGGL(fn, grid, dim3(WGM * WGN * 64), LDS, ctx->stream, kk);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
@@ -725,8 +782,50 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
   }
 }
 
-static int choose_cfg(int M, int N, int K, int batch, bool conv) {
+// Split-K by 2 pays when a 128-row tiling leaves about half the CUs idle and K is long: the M = 2048 level of the UNet
+// (16 x 8 tiles of 128x160, K = 5120..23040).  64-row tiles fill the chip there but move 46 flop per LDS-DMA byte and
+// are bound by the per-CU DMA rate; two 128-row half-K blocks move 71 flop/B.
+// The split-K hand-off goes through the XCD-private L2 without a device-scope release/acquire (which costs an L2
+// write-back per producer block and made split-K a net loss: 157 vs 160.5 steps/s).  That is only sound when the
+// two blocks of a pair share an XCD, i.e. when the dispatcher maps workgroup b to XCD b mod 8 - probed once here
+// with the hardware's XCC_ID register; any other mapping disables split-K.  The kernel re-checks the pair at run time.
+__global__ void k_probe_xcc(int* out) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 0xf);
+}
+static bool xcd_round_robin() {
+  static int ok = -1;
+  if (ok >= 0) return ok != 0;
+  ok = 0;
+  const int nb = 1024;
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, nb * sizeof(int)) != hipSuccess) return false;
+  std::vector<int> h(nb, -1);
+  hipLaunchKernelGGL(k_probe_xcc, dim3(nb), dim3(64), 0, 0, d);
+  if (hipMemcpy(h.data(), d, nb * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+    ok = 1;
+    for (int b = 0; b < nb; b++) if (h[b] < 0 || h[b] != h[b & 7]) ok = 0;
+    for (int i = 0; i < 8; i++) for (int j = 0; j < i; j++) if (h[i] == h[j]) ok = 0;
+  }
+  hipFree(d);
+  if (!ok && getenv("TSD_DEBUG_OCC")) fprintf(stderr, "[gemm] workgroup -> XCD mapping is not round-robin: split-K disabled\n");
+  return ok != 0;
+}
+extern "C" int tsd_debug_xcd_round_robin(void) { return xcd_round_robin() ? 1 : 0; }
+
+static bool want_splitk(int M, int N, int K, int batch, int rps) {
+  static const int on = getenv("TSD_GEMM_SPLITK") ? atoi(getenv("TSD_GEMM_SPLITK")) : 1;
+  // The decision must not depend on the batch size (bitwise batch invariance: a split changes the fp32 summation
+  // tree), so it keys on the layer: rows per sample (<= 256: the 16x16 level of a 64x64 latent), N and K.
+  if (!on || batch != 1 || N <= 16 || K < 4096 || rps <= 0 || rps > 256 || !xcd_round_robin()) return false;
+  const int BN = (N % 160 == 0) ? 160 : 128;
+  const int tiles = ceil_div(M, 128) * ceil_div(N, BN);
+  return tiles <= 256 && tiles % 8 == 0;
+}
+static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   if (N <= 16) return 4;
+  if (want_splitk(M, N, K, batch, rps)) return (N % 160 == 0) ? 5 : 8;
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
   // measured on MI355X (scripts/bench_gemm.py with REAL_EPI=1, pinned issue order):
@@ -761,7 +860,7 @@ static void cfg_wave_tile(int id, int* bmw, int* bnw) {
 int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups) {
   if (groups <= 0 || N % groups || (N & 7) || batch != 1) return 0;
   int bmw, bnw;
-  cfg_wave_tile(choose_cfg(M, N, K, batch, conv != 0), &bmw, &bnw);
+  cfg_wave_tile(choose_cfg(M, N, K, batch, conv != 0, rows_per_sample), &bmw, &bnw);
   const int cpg = N / groups;
   if (!bmw || bnw % cpg || rows_per_sample % bmw || M % rows_per_sample) return 0;
   return rows_per_sample / 32;  // one slab per 32-row epilogue pass, independent of the tile shape
@@ -769,7 +868,7 @@ int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sa
 
 template <bool CONV>
 static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
-  const int id = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV);
+  const int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? ((k.N % 160 == 0) ? 5 : 8) : choose_cfg(k.M, k.N, k.K, batch, CONV));
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
 
@@ -914,6 +1013,17 @@ extern "C" int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W,
   return TSD_OK;
 }
 
+static std::map<tsd_ctx*, int*> g_sk_flags;  // 4096 zeroed ints per context: one arrival flag per tile (re-armed by the
+                                             // consumers) and, at [4095], a count of hand-offs that timed out or crossed XCDs
+extern "C" int tsd_debug_splitk_errors(tsd_ctx* ctx) {
+  auto it = g_sk_flags.find(ctx);
+  if (it == g_sk_flags.end()) return 0;
+  int v = -1;
+  hipStreamSynchronize(ctx->stream);
+  if (hipMemcpy(&v, it->second + 4095, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
+}
+
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) TSD_FAIL(TSD_E_SHAPE, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.K % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: K=%d must be a multiple of 64 (pad at pack time)", a.K);
@@ -938,6 +1048,14 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
         a.gn_nslab != gemm_gnstats_slabs(a.M, a.N, a.K, a.batch, a.conv, a.gn_rows_per_sample, a.gn_groups) || a.gn_nslab <= 0)
       TSD_FAIL(TSD_E_ARG, "gemm: GroupNorm statistics requested for a shape/tile that cannot emit them");
   }
+  // split-K workspace (arena: the planning pass sees the same allocation) and the per-context arrival flags
+  float* sk_ws = nullptr;
+  const bool splitk = g_force_cfg < 0 && want_splitk(a.M, a.N, a.K, a.batch, a.rows_per_sample_hint);
+  if (splitk) {
+    const int BN = (a.N % 160 == 0) ? 160 : 128;
+    sk_ws = arena_alloc<float>(ctx, (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, BN) * 128 * BN);
+    if (!sk_ws) TSD_FAIL(TSD_E_ALLOC, "gemm: split-K workspace exhausted");
+  }
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, a.conv ? KC_CONV : KC_GEMM, a.M, a.N, a.K, a.batch);
   GemmK k;
@@ -951,5 +1069,14 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;
+  k.splitk = splitk ? 2 : 1; k.sk_ws = sk_ws; k.sk_flags = nullptr;
+  if (splitk) {
+    int*& f = g_sk_flags[ctx];
+    if (!f) {
+      HIP_TRY(hipMalloc((void**)&f, 4096 * sizeof(int)));
+      HIP_TRY(hipMemsetAsync(f, 0, 4096 * sizeof(int), ctx->stream));
+    }
+    k.sk_flags = f;
+  }
   return a.conv ? dispatch<true>(ctx, k, a.batch) : dispatch<false>(ctx, k, a.batch);
 }

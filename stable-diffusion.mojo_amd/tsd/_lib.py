@@ -96,6 +96,8 @@ def _declare(l):
         "tsd_dist_unique_id": ([vp], i), "tsd_dist_init": ([vp, i, i, vp], i),
         "tsd_dist_broadcast_weights": ([vp, i], i), "tsd_dist_finalize": ([vp], i),
         "tsd_flop_count": ([i, i, i], C.c_double),
+        "tsd_debug_splitk_errors": ([vp], i),
+        "tsd_debug_xcd_round_robin": ([], i),
         "tsd_debug_gemm_bench": ([vp, i, i, i, i, i, i, i, i, i, i, fp], i),
         "tsd_debug_attn_bench": ([vp, i, i, i, i, i, i, fp], i),
         "tsd_debug_gemm_check": ([vp, i, i, i, i, i, i, i, i, i, i, fp, fp], i),

@@ -284,3 +284,15 @@ def test_clip_forward_matches_oracle(gpu_ctx, tsd_mod):
     np.testing.assert_array_equal(longer[:4], one[:4])          # causal mask: earlier rows ignore later tokens
     assert not np.array_equal(longer[4:7], one[4:7])
     clip.model.close()
+
+
+def test_splitk_handoff_is_l2_local(gpu_ctx, tsd_mod, diffusion):
+    """The M = 2048 level runs split-K with an XCD-local hand-off: workgroups must map to XCDs round-robin, and after
+    a headline-size forward no hand-off may have timed out or paired blocks on different XCDs."""
+    from tsd._lib import lib
+    assert lib().tsd_debug_xcd_round_robin() == 1
+    lat, ctx = _inputs(8, 64, tag=730)
+    temb = np.stack([tsd_mod.get_time_embedding(500.0).reshape(320)] * 8)
+    a = diffusion.forward(lat, ctx, temb)
+    assert np.isfinite(a).all()
+    assert lib().tsd_debug_splitk_errors(gpu_ctx.h) == 0
