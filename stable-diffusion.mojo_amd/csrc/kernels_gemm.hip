@@ -821,7 +821,8 @@ static bool want_splitk(int M, int N, int K, int batch, int rps) {
   if (!on || batch != 1 || N <= 16 || K < 4096 || rps <= 0 || rps > 256 || !xcd_round_robin()) return false;
   const int BN = (N % 160 == 0) ? 160 : 128;
   const int tiles = ceil_div(M, 128) * ceil_div(N, BN);
-  return tiles <= 256 && tiles % 8 == 0;
+  static const int max_tiles = getenv("TSD_GEMM_SPLITK_TILES") ? atoi(getenv("TSD_GEMM_SPLITK_TILES")) : 256;
+  return tiles <= max_tiles && tiles % 8 == 0;
 }
 static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   if (N <= 16) return 4;
