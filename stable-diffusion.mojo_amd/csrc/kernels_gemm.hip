@@ -7,17 +7,22 @@
 // C[m][n] = epilogue( sum_k A[m][k] * W[n][k] )       ("NT": both operands K-contiguous)
 //   dense : A[m][k] row-major (optionally the channel-concat of two tensors)
 //   conv  : A row m = output pixel (b,oy,ox); k = (tap, cin) with the NHWC source read at
-//           (oy*stride-pad+kh, ox*stride-pad+kw); out-of-image taps read a zero page.
+//           (oy*stride-pad+kh, ox*stride-pad+kw); out-of-image taps are zero-filled by the DMA's range check.
 //
-// Design (CDNA4, wave64):
-//   * v_mfma_f32_16x16x32_f16, operands swapped (D = Wfrag x Afrag^T) so each lane ends up with
-//     ONE output row m and 4*FN CONSECUTIVE output columns n -> contiguous 8-byte stores per
-//     fragment and 4*FN*2 contiguous bytes per lane.  The column permutation that makes the
-//     4*FN columns consecutive is applied for free on the SOURCE address of the W-tile load.
-//   * Tiles staged with global_load_lds_dwordx4 (16 B/lane DMA straight into LDS, no VGPR
-//     round trip), 128-B rows XOR-swizzled by (row & 7) on the source side so every
-//     ds_read_b128 fragment read is bank-conflict-free; double-buffered, one barrier per K-tile.
-//   * XCD-aware bijective block remap so tiles sharing an A panel hit the same per-XCD L2.
+// Design (CDNA4, wave64) - DESIGN.md section 4.1 has the measurements behind each point:
+//   * v_mfma_f32_16x16x32_f16, operands swapped (D = Wfrag x Afrag^T) so each lane ends up with ONE output row m and
+//     4*FN CONSECUTIVE output columns n.  The column permutation that makes them consecutive is applied for free on
+//     the SOURCE address of the W-tile load.
+//   * Tiles staged by LDS-DMA through buffer descriptors (lds_dma.h): 16 B/lane straight into LDS, a 32-bit byte
+//     offset per DMA instruction + the K position in the scalar offset (no address VALU), 128-B rows XOR-swizzled by
+//     (row & 7) on the source side so every ds_read_b128 fragment read is bank-conflict-free.  LDS ring of NS slots,
+//     counted s_waitcnt vmcnt, one raw s_barrier per K-tile.
+//   * Pinned issue order in the K loop: all fragment reads, then the MFMAs with the next tile's DMA instructions
+//     dropped one at a time into their shadow.
+//   * Epilogue: residual tile prefetched before the DMA drain; per-column terms in the MFMA layout; per-wave LDS
+//     transpose to row-major so loads/stores are 16 B per lane over whole row segments; optional GroupNorm
+//     statistics (EPI_GNSTATS) for the consumer norm; split-K hand-off through the XCD-local L2 for the 16x16 level.
+//   * XCD-aware block -> tile map: the 8 XCDs own an (8/xn) x xn grid of the tile space chosen by operand footprint.
 #include <math.h>
 #include <stdlib.h>
 

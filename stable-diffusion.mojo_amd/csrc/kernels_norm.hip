@@ -5,11 +5,13 @@
 // Formula kept literal (App.A D12): y = (x - mu) / (sigma + eps) * gamma, population sigma,
 // eps added to sigma, scalar gamma, no beta.
 //
-// GroupNorm is two launches: per-slab partial (sum, sumsq) over full NHWC pixel rows (coalesced 16-B loads,
-// 4 in flight per thread, fp32 accumulation, deterministic - no atomics), then an apply pass whose blocks each
-// finish the statistics in double from the <= 64 slab partials and stream the tensor once.  The source may be the channel-concat
-// of two tensors (UNet skip connections, diffusion.mojo:253-270) so the concat is never
-// materialised for the normalised branch.
+// GroupNorm is an apply pass whose blocks each finish the statistics in double from per-(sample, slab, group)
+// (sum, sumsq) partials and stream the tensor once.  The partials normally come for free from the epilogue of the
+// GEMM/conv that produced the tensor (EPI_GNSTATS, one 32-row slab per epilogue pass - kernels_gemm.hip); otherwise
+// (channel-concat inputs, very large images) from `k_gn_partial` here: coalesced 16-B NHWC loads, 4 in flight per
+// thread, fp32 accumulation, no atomics.  The source may be the channel-concat of two tensors (UNet skip
+// connections, diffusion.mojo:253-270) so the concat is never materialised for the normalised branch.
+// LayerNorm: one group of LPR lanes per row for the UNet widths (k_layernorm_grp), one wave per row otherwise.
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
