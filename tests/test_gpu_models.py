@@ -296,3 +296,21 @@ def test_splitk_handoff_is_l2_local(gpu_ctx, tsd_mod, diffusion):
     a = diffusion.forward(lat, ctx, temb)
     assert np.isfinite(a).all()
     assert lib().tsd_debug_splitk_errors(gpu_ctx.h) == 0
+
+
+def test_native_rccl_path_single_rank(gpu_ctx, tsd_mod):
+    """The library's own RCCL weight broadcast (`tsd_dist_*`, librccl resolved with dlopen) on a one-rank communicator:
+    init -> ncclBroadcast of the packed blob -> finalize must succeed and leave the weights untouched."""
+    import ctypes as C
+    from tsd._lib import check, lib
+    enc = tsd_mod.Encoder(seed=SEED)
+    img = rng.uniform(SEED, 740, 3 * 64 * 64, 1.0).reshape(1, 3, 64, 64)
+    noise = rng.normal(SEED, 741, 4 * 8 * 8).reshape(1, 4, 8, 8)
+    before = enc.forward(img, noise)
+    uid = C.create_string_buffer(128)
+    check(lib().tsd_dist_unique_id(uid))
+    check(lib().tsd_dist_init(gpu_ctx.h, 0, 1, uid))
+    check(lib().tsd_dist_broadcast_weights(enc.model.h, 0))
+    check(lib().tsd_dist_finalize(gpu_ctx.h))
+    np.testing.assert_array_equal(enc.forward(img, noise), before)
+    enc.model.close()
