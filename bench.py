@@ -125,12 +125,19 @@ def main():
     import tsd
     tsd.set_strict(True)
     dist = None
+    # TSD_BENCH_DEVICE / TSD_BENCH_BACKEND exist only to exercise the N>1 code path on a one-GPU box (all ranks on one
+    # device, gloo for the control collectives); the real run is one rank per GPU over RCCL.
+    dev_index = int(os.environ.get("TSD_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("TSD_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    ctx = tsd.Context(local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend)
+    ctx = tsd.Context(dev_index)
     tsd.set_default_context(ctx)
 
     # weights: rank 0 random-initialises on the device; other ranks receive the packed blob over RCCL
@@ -140,7 +147,9 @@ def main():
     if world > 1:
         models = [unet.model] + ([dec.model] if dec is not None else [])
         try:
-            bcast_s, bcast_bytes = broadcast_weights(models, rank, world, local_rank)
+            if backend != "nccl":
+                raise RuntimeError("control-plane backend is not RCCL")
+            bcast_s, bcast_bytes = broadcast_weights(models, rank, world, dev_index)
             bcast_how = "rccl broadcast of the packed blobs from rank 0"
         except Exception as e:  # the timed path does not depend on it: the device RNG gives every rank the same weights
             print(f"rank {rank}: weight broadcast failed ({e!r}); initialising from the shared seed instead", file=sys.stderr)
@@ -182,7 +191,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     out_lat = sess.latents()
