@@ -64,11 +64,12 @@ struct GemmK {
 };
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float c = 0.7978845608028654f;  // sqrt(2/pi), helpers/utils.mojo:1914
-  float u = c * (x + 0.044715f * x * x * x);
-  float e = __expf(2.f * u);  // tanh(u) = 1 - 2/(e^{2u}+1)
-  float t = 1.f - 2.f / (e + 1.f);
-  return 0.5f * x * (1.f + t);
+  // 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + 2^(-2 u log2 e)), u = sqrt(2/pi) (x + 0.044715 x^3)  (helpers/utils.mojo:1914).
+  // One v_exp_f32 + one v_rcp_f32 (1 ulp) instead of expf + an IEEE division: the GEGLU epilogue evaluates this 80 times
+  // per lane and tile, and the division sequence alone made it cost more than the K loop of the short-K GEMM it ends.
+  const float c2 = -2.f * 0.7978845608028654f * 1.4426950408889634f;
+  const float t = __builtin_amdgcn_exp2f(c2 * (x + 0.044715f * x * x * x));
+  return x * __builtin_amdgcn_rcpf(1.f + t);
 }
 
 #ifdef TSD_GEMM_TS

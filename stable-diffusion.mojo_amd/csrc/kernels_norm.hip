@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
               float f = ((float)v[u][j] - mu[q][j]) * ri[q][j];
-              if (p.silu) f = f / (1.f + __expf(-f));
+              if (p.silu) f = f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));  // x*sigmoid(x): v_exp + v_rcp, no IEEE division
               o[j] = (half_t)f;
             }
             *(h8*)(p.y + ((int64_t)b * p.HW + pix) * p.ldy + ch * 8) = o;
