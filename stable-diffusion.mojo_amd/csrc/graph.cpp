@@ -128,7 +128,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
                            x.gn_nslab));  // :89,:116
   half_t* tok = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok);
   CatSrc a; a.p0 = h0; a.ld0 = C; a.C0 = C;
-  TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C));  // :117
+  TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C, nullptr, S));  // :117
   half_t* ln = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ln);
   half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
   const int Sp = round_up(S, 8);
@@ -138,7 +138,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   // ---- self attention (:122-126) ----
   TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C));
   a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C));  // q,k
+  TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C, nullptr, S));  // q,k
   {  // V^T[b] = W_v . ln_b^T  -> [B][C][S]
     GemmArgs g;
     g.A0 = w.sa_in.w + (int64_t)2 * C * w.sa_in.Kpad; g.lda0 = w.sa_in.Kpad; g.sA = 0;
@@ -156,12 +156,12 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   TSD_TRY(launch_flash_attention(ctx, fa));
   half_t* tok2 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok2);
   a.p0 = ao;
-  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C));
+  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C, nullptr, S));
   // ---- cross attention (:129-133) ----
   TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C));
   half_t* q = qk;  // reuse
   a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C));
+  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C, nullptr, S));
   CtxKV kv;
   if (pre) kv = *pre;  // context K / V^T of all nine blocks were projected in two batched GEMMs (g_unet_forward)
   else {
@@ -188,12 +188,12 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   TSD_TRY(launch_flash_attention(ctx, fa));
   half_t* tok3 = tok;  // tok (first residual) is dead after tok2 was produced
   a.p0 = ao;
-  TSD_TRY(g_linear(ctx, a, M, w.ca_out.w, w.ca_out.Kpad, C, C, w.ca_out.b, tok2, C, 0, tok3, C));
+  TSD_TRY(g_linear(ctx, a, M, w.ca_out.w, w.ca_out.Kpad, C, C, w.ca_out.b, tok2, C, 0, tok3, C, nullptr, S));
   // ---- GEGLU feed-forward (:136-143) ----
   TSD_TRY(launch_layernorm(ctx, tok3, M, C, C, 1e-5f, ln, C));
   half_t* gg = arena_alloc<half_t>(ctx, M * 4 * C); CHECK_ALLOC(gg);
   a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C));
+  TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S));
   half_t* tok4 = tok2;  // tok2 is dead after tok3
   CatSrc ag; ag.p0 = gg; ag.ld0 = 4 * C; ag.C0 = 4 * C;
   TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C, nullptr, S));

@@ -824,7 +824,8 @@ static bool want_splitk(int M, int N, int K, int batch, int rps) {
   static const int on = getenv("TSD_GEMM_SPLITK") ? atoi(getenv("TSD_GEMM_SPLITK")) : 1;
   // The decision must not depend on the batch size (bitwise batch invariance: a split changes the fp32 summation
   // tree), so it keys on the layer: rows per sample (<= 256: the 16x16 level of a 64x64 latent), N and K.
-  if (!on || batch != 1 || N <= 16 || K < 4096 || rps <= 0 || rps > 256 || !xcd_round_robin()) return false;
+  static const int min_k = getenv("TSD_GEMM_SPLITK_MINK") ? atoi(getenv("TSD_GEMM_SPLITK_MINK")) : 4096;
+  if (!on || batch != 1 || N <= 16 || K < min_k || rps <= 0 || rps > 256 || !xcd_round_robin()) return false;
   const int BN = (N % 160 == 0) ? 160 : 128;
   const int tiles = ceil_div(M, 128) * ceil_div(N, BN);
   static const int max_tiles = getenv("TSD_GEMM_SPLITK_TILES") ? atoi(getenv("TSD_GEMM_SPLITK_TILES")) : 256;
