@@ -122,6 +122,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     B, L, T = args.batch, args.latent, args.tokens
 
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before anything initialises HIP (see tsd/_lib.py)
     import tsd
     tsd.set_strict(True)
     dist = None

@@ -1,6 +1,7 @@
 // runtime.cpp - context, error string, workspace arena, staging.  No CPU fallback anywhere: if HIP
 // reports no device every compute entry point fails with TSD_E_HIP.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -26,6 +27,9 @@ extern "C" int tsd_device_count(void) {
 extern "C" int tsd_ctx_create(int device, tsd_ctx** out) {
   if (!out) TSD_FAIL(TSD_E_ARG, "tsd_ctx_create: out is NULL");
   *out = nullptr;
+  // kernel arguments in device memory (see tsd/_lib.py): effective when this is the process's first HIP call; hosts that
+  // initialise HIP earlier export HIP_FORCE_DEV_KERNARG=1 themselves
+  setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     TSD_FAIL(TSD_E_HIP, "tsd_ctx_create: no HIP device visible (libtsd has no CPU fallback)");

@@ -13,6 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtsd.so")
 
 TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE = 0, -1, -2, -3, -4, -5, -6
+# Kernel arguments in device memory instead of host-coherent memory: every kernel starts by reading its ~200 B argument
+# block, and fetching it across the host link costs ~2 us per launch (measured: 169 -> 177 steps/s).  The HIP runtime
+# reads the switch when it initialises, so it goes into the environment as soon as this package is imported - before
+# libtsd.so (or torch, in the multi-GPU bench) makes the process's first HIP call.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 MODEL_DIFFUSION, MODEL_DECODER, MODEL_ENCODER, MODEL_CLIP = 1, 2, 3, 4
 
 
