@@ -407,50 +407,41 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 
   TS_MARK(2);
   // ---- split-K hand-off ---------------------------------------------------------------------
+  // Placement-independent publish (cdna_hip_programming.md, split-K rule 2): the partial tile leaves through sc1
+  // (write-through to memory) buffer stores, every storing wave drains its stores, one relaxed agent-scope flag store
+  // publishes it; the consumer polls relaxed and reads the partial back with sc1 loads.  No device-scope fence
+  // (`__threadfence()` = L2 write-back per producer block made split-K a net loss: 157 vs 160.5 steps/s).  Keeping the
+  // pair on one XCD is only a speed choice.
   if (p.splitk > 1) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
     // partial tile in the accumulator layout: (fragment, lane) -> 16 B, so every wave instruction moves 1 KiB contiguous
     float* wsw = p.sk_ws + ((long long)(tm * p.tiles_n + tn) * NW + wave) * (FM * FN * 256);
+    const rsrc_t rws = make_rsrc(wsw, FM * FN * 1024);
     int* flag = p.sk_flags + tm * p.tiles_n + tn;
     if (ks) {  // producer: second half of K
       wait_vmcnt<0>();  // dead tail DMA has landed before the wave may end
 #pragma unroll
       for (int a = 0; a < FM; a++)
 #pragma unroll
-        for (int b = 0; b < FN; b++) *(f4*)(wsw + ((a * FN + b) * 64 + lane) * 4) = acc[a][b];
-#ifdef TSD_SPLITK_AGENT_FENCE
-      __threadfence();  // partial visible device-wide before the flag
-#else
-      wait_vmcnt<0>();  // stores acknowledged by the XCD's L2, which the partner block (same XCD) reads from
-#endif
+        for (int b = 0; b < FN; b++)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[a][b]), rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the flag
       __syncthreads();
-      if (tid == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        __hip_atomic_store(flag, 1 + (int)(xcc & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    if (tid == 0) {  // consumer: bounded wait for the partner (all 2*ntile blocks are co-resident: ntile*2 <= CU count)
+    if (tid == 0) {  // consumer: bounded relaxed poll (producers have the lower block ids: always resident first)
       int spins = 0;
-      int f;
-      while ((f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(4);
-      unsigned xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      if (f == 0 || f - 1 != (int)(xcc & 0xf)) atomicAdd(&p.sk_flags[4095], 1);  // timeout, or the pair is split across XCDs:
-                                                                                 // tsd_debug_splitk_errors() reports it
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(4);
+      if (spins >= (1 << 18)) atomicAdd(&p.sk_flags[4095], 1);  // timed out: tsd_debug_splitk_errors() reports it
     }
     __syncthreads();
-#ifdef TSD_SPLITK_AGENT_FENCE
-    __threadfence();
-#else
-    asm volatile("" ::: "memory");  // this CU's L1 holds no line of the workspace yet (invalidated at kernel start): the loads go to L2
-#endif
 #pragma unroll
     for (int a = 0; a < FM; a++)
 #pragma unroll
       for (int b = 0; b < FN; b++) {
-        const f4 v = __builtin_nontemporal_load((const f4*)(wsw + ((a * FN + b) * 64 + lane) * 4));
-        acc[a][b] += v;  // fixed order: first half + second half
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
+        acc[a][b] += __builtin_bit_cast(f4, v);  // fixed order: first half + second half
       }
     if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
   }
@@ -791,10 +782,8 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
 // Split-K by 2 pays when a 128-row tiling leaves about half the CUs idle and K is long: the M = 2048 level of the UNet
 // (16 x 8 tiles of 128x160, K = 5120..23040).  64-row tiles fill the chip there but move 46 flop per LDS-DMA byte and
 // are bound by the per-CU DMA rate; two 128-row half-K blocks move 71 flop/B.
-// The split-K hand-off goes through the XCD-private L2 without a device-scope release/acquire (which costs an L2
-// write-back per producer block and made split-K a net loss: 157 vs 160.5 steps/s).  That is only sound when the
-// two blocks of a pair share an XCD, i.e. when the dispatcher maps workgroup b to XCD b mod 8 - probed once here
-// with the hardware's XCC_ID register; any other mapping disables split-K.  The kernel re-checks the pair at run time.
+// Workgroup -> XCD placement probe (HW_REG_XCC_ID).  The split-K hand-off is placement-independent (sc1 stores/loads),
+// so this only tells whether the same-XCD pairing of its two blocks - a speed choice - holds on this device.
 __global__ void k_probe_xcc(int* out) {
   unsigned x;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -825,7 +814,7 @@ static bool want_splitk(int M, int N, int K, int batch, int rps) {
   // The decision must not depend on the batch size (bitwise batch invariance: a split changes the fp32 summation
   // tree), so it keys on the layer: rows per sample (<= 256: the 16x16 level of a 64x64 latent), N and K.
   static const int min_k = getenv("TSD_GEMM_SPLITK_MINK") ? atoi(getenv("TSD_GEMM_SPLITK_MINK")) : 4096;
-  if (!on || batch != 1 || N <= 16 || K < min_k || rps <= 0 || rps > 256 || !xcd_round_robin()) return false;
+  if (!on || batch != 1 || N <= 16 || K < min_k || rps <= 0 || rps > 256) return false;
   const int BN = (N % 160 == 0) ? 160 : 128;
   const int tiles = ceil_div(M, 128) * ceil_div(N, BN);
   static const int max_tiles = getenv("TSD_GEMM_SPLITK_TILES") ? atoi(getenv("TSD_GEMM_SPLITK_TILES")) : 256;

@@ -286,16 +286,18 @@ def test_clip_forward_matches_oracle(gpu_ctx, tsd_mod):
     clip.model.close()
 
 
-def test_splitk_handoff_is_l2_local(gpu_ctx, tsd_mod, diffusion):
-    """The M = 2048 level runs split-K with an XCD-local hand-off: workgroups must map to XCDs round-robin, and after
-    a headline-size forward no hand-off may have timed out or paired blocks on different XCDs."""
+def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
+    """The 16x16 level runs split-K with an in-launch hand-off (sc1 stores -> relaxed flag -> sc1 loads): after a
+    headline-size forward no consumer may have timed out waiting for its partner, and the result is reproducible."""
     from tsd._lib import lib
-    assert lib().tsd_debug_xcd_round_robin() == 1
     lat, ctx = _inputs(8, 64, tag=730)
     temb = np.stack([tsd_mod.get_time_embedding(500.0).reshape(320)] * 8)
     a = diffusion.forward(lat, ctx, temb)
     assert np.isfinite(a).all()
+    for _ in range(3):
+        np.testing.assert_array_equal(diffusion.forward(lat, ctx, temb), a)
     assert lib().tsd_debug_splitk_errors(gpu_ctx.h) == 0
+    assert lib().tsd_debug_xcd_round_robin() in (0, 1)   # informational: same-XCD pairing is a speed choice only
 
 
 def test_native_rccl_path_single_rank(gpu_ctx, tsd_mod):
