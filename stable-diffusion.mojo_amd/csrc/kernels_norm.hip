@@ -27,6 +27,7 @@ struct GnK {
   float* stats;    // [B][G][2]         (mean, gamma/(sigma+eps))
   float eps, gamma;
   int silu;
+  int stats_ready;  // stats[] already holds the finished (mean, scale) pairs (k_gn_finalize ran)
   half_t* y; int ldy;
   int apply_pixels;
 };
@@ -111,36 +112,49 @@ __global__ __launch_bounds__(256) void k_gn_partial(const GnK p) {
   }
 }
 
+// Finish the statistics of 32 groups [g0, g0+32) of sample b from the slab partials: 8 lanes per group stride over the
+// slabs, fixed-order butterfly in double => deterministic.  Writes (mean, gamma/(sigma+eps)) pairs to out[2*g..].
+__device__ __forceinline__ void gn_finish_groups(const GnK& p, int b, int g0, int tid, float* out) {
+  const int g = g0 + (tid >> 3), sl = tid & 7;
+  double t1 = 0.0, t2 = 0.0;
+  if (g < p.G)
+#pragma unroll 4
+    for (int s = sl; s < p.nslab; s += 8) {
+      const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
+      t1 += (double)o[0];
+      t2 += (double)o[1];
+    }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    t1 += __shfl_xor(t1, o);
+    t2 += __shfl_xor(t2, o);
+  }
+  if (g < p.G && sl == 0) {
+    const double n = (double)p.cpg * (double)p.HW;
+    const double mu = t1 / n;
+    double var = t2 / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    out[2 * g] = (float)mu;
+    out[2 * g + 1] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));  // eps added to sigma (helpers/utils.mojo:1871-1873)
+  }
+}
+
+// Separate finalize launch, used when (slabs x groups) is large: then every apply block re-reducing the partials would
+// read as much as its payload (128 slabs x 32 groups = 32 KB per 30 KB of pixels at 320x64^2; 10x that for the output
+// layer's 320 groups).  One block per (32 groups, sample).
+__global__ __launch_bounds__(256) void k_gn_finalize(const GnK p) {
+  gn_finish_groups(p, blockIdx.y, blockIdx.x * 32, threadIdx.x, p.stats + (int64_t)blockIdx.y * p.G * 2);
+}
+
 __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
   extern __shared__ __attribute__((aligned(16))) char smem_gn[];
   float* st = (float*)smem_gn;  // [G][2] (mean, gamma/(sigma+eps))
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  // every block finishes the statistics itself (a few KB of partials from L2) - no separate finalize launch.
-  // 8 lanes per group stride over the slabs; fixed-order butterfly in double => deterministic.
-  for (int g0 = 0; g0 < p.G; g0 += 32) {
-    const int g = g0 + (tid >> 3), sl = tid & 7;
-    double t1 = 0.0, t2 = 0.0;
-    if (g < p.G)
-#pragma unroll 4
-      for (int s = sl; s < p.nslab; s += 8) {
-        const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
-        t1 += (double)o[0];
-        t2 += (double)o[1];
-      }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-      t1 += __shfl_xor(t1, o);
-      t2 += __shfl_xor(t2, o);
-    }
-    if (g < p.G && sl == 0) {
-      const double n = (double)p.cpg * (double)p.HW;
-      const double mu = t1 / n;
-      double var = t2 / n - mu * mu;
-      if (var < 0.0) var = 0.0;
-      st[2 * g] = (float)mu;
-      st[2 * g + 1] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));  // eps added to sigma (helpers/utils.mojo:1871-1873)
-    }
+  if (p.stats_ready) {  // finished by k_gn_finalize
+    for (int i = tid; i < 2 * p.G; i += 256) st[i] = p.stats[(int64_t)b * p.G * 2 + i];
+  } else {  // few slabs: every block finishes the statistics itself (a few KB of partials from L2), no extra launch
+    for (int g0 = 0; g0 < p.G; g0 += 32) gn_finish_groups(p, b, g0, tid, st);
   }
   __syncthreads();
   const GnMap m = gn_map(p.C, tid);
@@ -213,6 +227,11 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
   if (!have_stats) {
     hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
+    HIP_TRY(hipGetLastError());
+  }
+  k.stats_ready = (int64_t)k.nslab * groups >= 2048 ? 1 : 0;
+  if (k.stats_ready) {
+    hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
