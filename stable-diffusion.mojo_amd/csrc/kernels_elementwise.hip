@@ -295,9 +295,14 @@ int launch_time_embedding(tsd_ctx* ctx, const float* t, float t_scalar, int B, f
 }
 
 // ---- tiny-M linear (time MLP and the nine 1280->C time projections; SURVEY.md App.D K8) ----------
-// y[b][n] = sum_k act(x[b][k]) * W[n][k] + bias[n], B <= 16.  Weights are streamed once
-// (HBM-bound GEMV); act(x) is staged in LDS per block.
+// y[b][n] = sum_k act(x[b][k]) * W[n][k] + bias[n], B <= 16.  Weights are streamed once (HBM-bound GEMV); act(x) is staged
+// in LDS per block.  A block owns 16 output columns, a wave 4 of them with 16 lanes per column: each lane covers K/16 of
+// the row with all its 16-B weight loads issued up front, and a column is finished by a 4-step exchange inside its 16
+// lanes (the earlier one-column-per-wave layout needed 6 LDS-crossbar steps for every (sample, column) pair: 22 us
+// floor per launch whatever the size).
 constexpr int SL_MAXB = 16;
+constexpr int SL_KIT = 16;  // 16-B weight chunks per lane held in registers: K <= 16 * 128 = 2048 per pass
+template <int NB>
 __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ x, int B, int K, int ldx,
                                                       const half_t* __restrict__ w, int ldw,
                                                       const float* __restrict__ bias, int N, int silu_in,
@@ -305,8 +310,7 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem_sl[];
   float* xs = (float*)smem_sl;  // [B][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // activations -> LDS (with the fused SiLU): batches of 8 independent 16-B loads per thread (K % 4 == 0), so the
-  // staging costs a couple of L2 round trips instead of one per element
+  // activations -> LDS (with the fused SiLU): batches of 8 independent 16-B loads per thread (K % 4 == 0)
   const int nvec = (B * K) >> 2;
   for (int i0 = tid; i0 < nvec; i0 += 256 * 8) {
     f4 v[8];
@@ -322,62 +326,52 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
     for (int u = 0; u < 8; u++) {
       const int i = i0 + u * 256;
       if (i < nvec) {
-        if (silu_in) v[u] = f4{silu_f(v[u][0]), silu_f(v[u][1]), silu_f(v[u][2]), silu_f(v[u][3])};
+        if (silu_in) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[u][j] = v[u][j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[u][j]));
+        }
         *(f4*)(xs + i * 4) = v[u];
       }
     }
   }
   __syncthreads();
-  // Each wave owns 4 of the block's 16 output columns.  All of its weight loads (4 columns x up to 4 K-slices of
-  // 512) are issued before any arithmetic, so the block pays one HBM round trip instead of one per slice.
-  const int n_per_block = 16;
-  constexpr int SL_COLS = 4, SL_KIT = 4;  // K <= 2048 in one shot; longer rows loop
-  for (int kbase = 0; kbase < K; kbase += 512 * SL_KIT) {
-    h8 wv[SL_COLS][SL_KIT];
+  const int col = lane >> 4, sub = lane & 15;  // column within the wave's 4, lane within the column's 16
+  const int n = blockIdx.x * 16 + wave * 4 + col;
+  const half_t* wr = w + (int64_t)min(n, N - 1) * ldw;
+  float acc[NB];
 #pragma unroll
-    for (int j = 0; j < SL_COLS; j++) {
-      const int n = min(blockIdx.x * n_per_block + wave + 4 * j, N - 1);
-      const half_t* wr = w + (int64_t)n * ldw;
+  for (int b = 0; b < NB; b++) acc[b] = 0.f;
+  for (int kbase = 0; kbase < K; kbase += 128 * SL_KIT) {
+    h8 wv[SL_KIT];
 #pragma unroll
-      for (int it = 0; it < SL_KIT; it++) {
-        const int k0 = kbase + it * 512 + lane * 8;
-        wv[j][it] = k0 < K ? *(const h8*)(wr + k0) : h8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
+    for (int it = 0; it < SL_KIT; it++) {
+      const int k0 = kbase + it * 128 + sub * 8;
+      wv[it] = k0 < K ? *(const h8*)(wr + k0) : h8{0, 0, 0, 0, 0, 0, 0, 0};
     }
 #pragma unroll
-    for (int j = 0; j < SL_COLS; j++) {
-      const int n = blockIdx.x * n_per_block + wave + 4 * j;
-      float acc[SL_MAXB];
+    for (int it = 0; it < SL_KIT; it++) {
+      const int k0 = kbase + it * 128 + sub * 8;
+      if (k0 < K) {
+        const h8 q = wv[it];
 #pragma unroll
-      for (int b = 0; b < SL_MAXB; b++) acc[b] = 0.f;
-#pragma unroll
-      for (int it = 0; it < SL_KIT; it++) {
-        const int k0 = kbase + it * 512 + lane * 8;
-        if (k0 < K) {
-#pragma unroll
-          for (int b = 0; b < SL_MAXB; b++) {
-            if (b < B) {
-              const f4 x0 = *(const f4*)(xs + b * K + k0), x1 = *(const f4*)(xs + b * K + k0 + 4);
-              const h8 q = wv[j][it];
-              acc[b] += (float)q[0] * x0[0] + (float)q[1] * x0[1] + (float)q[2] * x0[2] + (float)q[3] * x0[3] +
-                        (float)q[4] * x1[0] + (float)q[5] * x1[1] + (float)q[6] * x1[2] + (float)q[7] * x1[3];
-            }
+        for (int b = 0; b < NB; b++)
+          if (b < B) {
+            const f4 x0 = *(const f4*)(xs + b * K + k0), x1 = *(const f4*)(xs + b * K + k0 + 4);
+            acc[b] += (float)q[0] * x0[0] + (float)q[1] * x0[1] + (float)q[2] * x0[2] + (float)q[3] * x0[3] +
+                      (float)q[4] * x1[0] + (float)q[5] * x1[1] + (float)q[6] * x1[2] + (float)q[7] * x1[3];
           }
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < SL_MAXB; b++) {
-        if (b < B) {
-          const float s = wave_sum(acc[b]);
-          if (lane == 0 && n < N) {
-            float* yp = y + (int64_t)b * ldy + n;
-            *yp = kbase == 0 ? s + (bias ? bias[n] : 0.f) : *yp + s;
-          }
-        }
       }
     }
   }
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    float s = acc[b];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);  // within the column's 16 lanes
+    if (sub == 0 && b < B && n < N) y[(int64_t)b * ldy + n] = s + (bias ? bias[n] : 0.f);
+  }
 }
+
 int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
                         int N, int silu_in, float* y, int ldy) {
   if (B > SL_MAXB) TSD_FAIL(TSD_E_SHAPE, "small_linear: B=%d > %d", B, SL_MAXB);
@@ -385,14 +379,22 @@ int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, con
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_SMALL_LINEAR, B, N, K, 1);
   const size_t lds = (size_t)B * K * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_small_linear, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
   if (lds > 160 * 1024) TSD_FAIL(TSD_E_SHAPE, "small_linear: B*K too large for LDS");
-  hipLaunchKernelGGL(k_small_linear, dim3(ceil_div(N, 16)), dim3(256), lds, ctx->stream, x, B, K, ldx, w, ldw, bias, N,
-                     silu_in, y, ldy);
+  static bool attr_set[5] = {false, false, false, false, false};
+  const int slot = B <= 1 ? 0 : B <= 2 ? 1 : B <= 4 ? 2 : B <= 8 ? 3 : 4;
+  auto launch = [&](auto fn) -> int {
+    if (!attr_set[slot]) {
+      HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(ceil_div(N, 16)), dim3(256), lds, ctx->stream, x, B, K, ldx, w, ldw, bias, N, silu_in, y, ldy);
+    return TSD_OK;
+  };
+  if (B <= 1) TSD_TRY(launch(k_small_linear<1>));
+  else if (B <= 2) TSD_TRY(launch(k_small_linear<2>));
+  else if (B <= 4) TSD_TRY(launch(k_small_linear<4>));
+  else if (B <= 8) TSD_TRY(launch(k_small_linear<8>));
+  else TSD_TRY(launch(k_small_linear<16>));
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
