@@ -102,8 +102,8 @@ def cpu_baseline(L, T):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE config 2: 8)")
     ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512)")
     ap.add_argument("--tokens", type=int, default=77)
