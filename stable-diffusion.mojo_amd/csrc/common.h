@@ -52,6 +52,8 @@ struct tsd_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Arena arena;
+  int* sk_flags = nullptr;  // 4096 zeroed ints, allocated on first use: one split-K arrival flag per tile (re-armed by the
+                            // consumers) and, at [4095], a count of hand-offs that timed out
   half_t* zeros = nullptr;  // 4 KiB: [0,2048) zeros (padded im2col taps / head dims); [2048,2176) fp16 ones
   void* staging = nullptr;  // device staging for host<->device copies
   size_t staging_cap = 0;

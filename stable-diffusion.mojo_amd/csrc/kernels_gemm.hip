@@ -27,7 +27,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <map>
 #include <vector>
 
 #include "common.h"
@@ -1010,14 +1009,11 @@ extern "C" int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W,
   return TSD_OK;
 }
 
-static std::map<tsd_ctx*, int*> g_sk_flags;  // 4096 zeroed ints per context: one arrival flag per tile (re-armed by the
-                                             // consumers) and, at [4095], a count of hand-offs that timed out or crossed XCDs
 extern "C" int tsd_debug_splitk_errors(tsd_ctx* ctx) {
-  auto it = g_sk_flags.find(ctx);
-  if (it == g_sk_flags.end()) return 0;
+  if (!ctx || !ctx->sk_flags) return 0;
   int v = -1;
   hipStreamSynchronize(ctx->stream);
-  if (hipMemcpy(&v, it->second + 4095, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(&v, ctx->sk_flags + 4095, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return v;
 }
 
@@ -1068,12 +1064,11 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.gn_nslab = a.gn_nslab;
   k.splitk = splitk ? 2 : 1; k.sk_ws = sk_ws; k.sk_flags = nullptr;
   if (splitk) {
-    int*& f = g_sk_flags[ctx];
-    if (!f) {
-      HIP_TRY(hipMalloc((void**)&f, 4096 * sizeof(int)));
-      HIP_TRY(hipMemsetAsync(f, 0, 4096 * sizeof(int), ctx->stream));
+    if (!ctx->sk_flags) {
+      HIP_TRY(hipMalloc((void**)&ctx->sk_flags, 4096 * sizeof(int)));
+      HIP_TRY(hipMemsetAsync(ctx->sk_flags, 0, 4096 * sizeof(int), ctx->stream));
     }
-    k.sk_flags = f;
+    k.sk_flags = ctx->sk_flags;
   }
   return a.conv ? dispatch<true>(ctx, k, a.batch) : dispatch<false>(ctx, k, a.batch);
 }

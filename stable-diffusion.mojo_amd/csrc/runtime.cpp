@@ -59,6 +59,7 @@ extern "C" int tsd_ctx_destroy(tsd_ctx* c) {
   if (c->arena.base) hipFree(c->arena.base);
   if (c->staging) hipFree(c->staging);
   if (c->zeros) hipFree(c->zeros);
+  if (c->sk_flags) hipFree(c->sk_flags);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);
