@@ -190,7 +190,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
       qk(t & 1, s[0], s[1]);
     } else {
       if (t + 2 < ntiles) stage(t + 2, cur >= 1 ? cur - 1 : 2);  // slot of tile t-1 (free since the last barrier)
-      if (t + 1 < ntiles) qk(cur == 2 ? 0 : cur + 1, sn[0], sn[1]);
     }
     const char* sV = smem + (NST == 2 ? (t & 1) : cur) * BUF_BYTES + K_BYTES;
     // lane (hi, r) of block kb holds key kb*32 + (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
@@ -205,12 +204,39 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
         }
     }
     // ---- online softmax (fp32) ----------------------------------------------------------------
-    float mx = s[0][0];
+    // NST == 3: the NEXT tile's S^T MFMAs are issued one at a time between pieces of this tile's softmax, in a pinned
+    // order, so the matrix pipe works while the VALU does max / exp2 (the last tile computes a dummy next tile).
+    h8 kf[NST == 3 ? KSTEPS : 1][2];
+    float mx;
+    if (NST == 3) {
+      const char* sKn = smem + (cur == 2 ? 0 : cur + 1) * BUF_BYTES;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++)
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        kf[ks][0] = *(const h8*)(sKn + ((l31)*KPITCH + ks * 2 + hi) * 16);
+        kf[ks][1] = *(const h8*)(sKn + ((32 + l31) * KPITCH + ks * 2 + hi) * 16);
+      }
+      const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+      sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[0], z, 0, 0, 0);
+      float m0 = s[0][0];
 #pragma unroll
-      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+      for (int r = 1; r < 16; r++) m0 = fmaxf(m0, s[0][r]);
+      __builtin_amdgcn_sched_barrier(0);
+      sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[0], z, 0, 0, 0);
+      float m1 = s[1][0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) m1 = fmaxf(m1, s[1][r]);
+      mx = fmaxf(m0, m1);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+    }
     if (__any(mx > m_run)) {  // wave-uniform: rescale only when some row's running max actually grew
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
@@ -229,28 +255,68 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     const float nmc = -m_run * p.c;
     const f2 c2 = {p.c, p.c}, m2 = {nmc, nmc};
     f2 psum2 = {0.f, 0.f};
-    h8 pf[4];
+    // P^T chunk kq (8 keys per lane) feeds the P.V MFMAs of chunk kq only, so the exponentials of chunk kq+1 are issued
+    // between those MFMAs: the matrix pipe works through chunk kq while the VALU (exp2 is the slow part) produces the
+    // next one.  The issue order is pinned; left to itself the compiler emits all 32 exponentials and then all MFMAs.
+    auto p_chunk = [&](int kq) {
+      h8 pf;
+      const int kb = kq >> 1, r0 = (kq & 1) * 8;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        f2 e = {s[kb][r], s[kb][r + 1]};
+      for (int r = 0; r < 8; r += 2) {
+        f2 e = {s[kb][r0 + r], s[kb][r0 + r + 1]};
         e = e * c2 + m2;  // v_pk_fma_f32
         const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
         if (!ONES_ROW) psum2 += f2{p0, p1};
-        pf[kb * 2 + (r >> 3)][r & 7] = (half_t)p0;
-        pf[kb * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
+        pf[r] = (half_t)p0;
+        pf[r + 1] = (half_t)p1;
       }
-    if (!ONES_ROW) l_run += psum2[0] + psum2[1];
-    // ---- O^T += V^T . P^T ------------------------------------------------------------------------
+      return pf;
+    };
+    auto v_frag = [&](int kq, h8 (&vf)[DBLK]) {
 #pragma unroll
-    for (int d = 0; d < DBLK; d++) {
+      for (int d = 0; d < DBLK; d++) vf[d] = *(const h8*)(sV + (d * 32 + l31) * 128 + (((kq * 2 + hi) ^ vkey) << 4));
+    };
+    h8 vf_cur[DBLK], vf_next[DBLK];
+    v_frag(0, vf_cur);
+    h8 pf_cur;
+    if (NST == 3) {
+      constexpr int PER = (2 * KSTEPS - 2) / 4;  // remaining next-tile MFMAs per pair of exponentials
+      static_assert(NST != 3 || (2 * KSTEPS - 2) % 4 == 0, "next-tile MFMAs must split evenly over chunk 0");
 #pragma unroll
-      for (int kq = 0; kq < 4; kq++) {  // kq = kb*2 + half ; logical chunk = kq*2 + hi
-        const h8 vf = *(const h8*)(sV + (d * 32 + l31) * 128 + (((kq * 2 + hi) ^ vkey) << 4));
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kq], o[d], 0, 0, 0);
+      for (int i = 0; i < 4; i++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = i * PER; j < (i + 1) * PER; j++) {
+          const int ks = 1 + (j >> 1), blk = j & 1;
+          sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][blk], qf[ks], sn[blk], 0, 0, 0);
+        }
+        const int r = i * 2;
+        f2 e = {s[0][r], s[0][r + 1]};
+        e = e * c2 + m2;
+        const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+        if (!ONES_ROW) psum2 += f2{p0, p1};
+        pf_cur[r] = (half_t)p0;
+        pf_cur[r + 1] = (half_t)p1;
       }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      pf_cur = p_chunk(0);
     }
+#pragma unroll
+    for (int kq = 0; kq < 4; kq++) {  // kq = kb*2 + half ; logical chunk = kq*2 + hi
+      if (kq < 3) v_frag(kq + 1, vf_next);  // LDS latency hides under this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_cur[0], pf_cur, o[0], 0, 0, 0);
+      h8 pf_next = pf_cur;
+      if (kq < 3) pf_next = p_chunk(kq + 1);
+#pragma unroll
+      for (int d = 1; d < DBLK; d++) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_cur[d], pf_cur, o[d], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      pf_cur = pf_next;
+#pragma unroll
+      for (int d = 0; d < DBLK; d++) vf_cur[d] = vf_next[d];
+    }
+    if (!ONES_ROW) l_run += psum2[0] + psum2[1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur = (cur == 2) ? 0 : cur + 1;
