@@ -113,6 +113,8 @@ def main():
                     help="also time the loop with classifier-free guidance (UNet batch 2B per step) as an extra field")
     ap.add_argument("--img2img", action="store_true",
                     help="also time the VAE encoder and report BASELINE configs[3] (encoder + 30 steps + decoder) as an extra field")
+    ap.add_argument("--sd15", action="store_true",
+                    help="also time BASELINE configs[4]: the full-size (860 M parameter) UNet at batch 4, as an extra field")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -259,6 +261,30 @@ def main():
                 s2.step((2 + i) % n_sched)
             cfg_ms = ctx.timer_stop() / K
             s2.close()
+        # ---- BASELINE configs[4]: full-size (SD-1.5-sized) UNet, batch 4, same 50-step schedule ----
+        sd15 = None
+        if args.sd15:
+            B5 = 4
+            big = tsd.Diffusion(seed=SEED, ctx=ctx, variant="diffusion_sd15")
+            s5 = tsd.Session(big.model, None, B5, L, T, cfg=False)
+            s5.set_schedule(1000, n_sched, 0)
+            s5.upload(lat[:B5], cx[:B5], None, noise[:, :B5])
+            for i in range(3):
+                s5.step(i)
+            ctx.synchronize()
+            ctx.timer_start()
+            for i in range(K):
+                s5.step((3 + i) % n_sched)
+            ms5 = ctx.timer_stop() / K
+            gf5 = tsd.flop_count("diffusion_sd15", L, T)
+            sd15 = {"workload": f"full-size UNet (859 M parameters, 12 encoders / bottleneck / 12 decoders), latent 4x{L}x{L}, "
+                                f"batch {B5}, random-init weights (BASELINE configs[4]; graph not defined by the reference)",
+                    "steps_per_s": round(1e3 / ms5, 3), "ms_per_step": round(ms5, 4),
+                    "algorithmic_gflop_per_step": round(gf5 * B5, 1),
+                    "frac_of_fp16_mfma_peak_whole_step": round(gf5 * B5 / ms5 / PEAK_FP16_TFLOPS, 4),
+                    "output_finite": bool(np.isfinite(s5.latents()).all())}
+            s5.close()
+            big.model.close()
         # ---- BASELINE configs[3] (img2img): VAE encoder on B x (3,512,512) + strength 0.6 of the schedule + decoder ----
         enc_ms = None
         if args.img2img and dec is not None:
@@ -290,6 +316,7 @@ def main():
             "img2img_config4": None if enc_ms is None else {
                 "encode_ms_host_boundary": round(enc_ms, 3), "steps": int(n_sched * 0.6),
                 "images_per_s": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
+            "sd15_config5": sd15,
             "event_ms_per_step": round(ev_ms / K, 4), "output_finite": finite,
             "frac_of_fp16_mfma_peak_whole_step": round(whole_frac, 4),
             "weight_broadcast_s": round(bcast_s, 4), "weight_broadcast_bytes": bcast_bytes, "weight_broadcast": bcast_how,

@@ -160,7 +160,12 @@ int tsd_vae_attention_block_f32(tsd_ctx* ctx, const float* x, int C, int H, int 
 
 /* ---- module level: device-resident weights (the measured path) ------------------------ */
 
-typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4 } tsd_model_kind;
+/* TSD_MODEL_DIFFUSION_SD15: the full-size (860 M parameter) UNet of BASELINE.json configs[4] - the 12-encoder /
+ * bottleneck / 12-decoder layout the reference's 23-layer graph (diffusion.mojo:177-201) was trimmed from, built from
+ * the reference's own blocks (Unet_Residual_Block diffusion.mojo:34-72, Unet_Attention_Block :87-147, Upsample
+ * :149-160 followed by a 3x3 conv).  It is not defined by the reference: throughput stress configuration only; every
+ * entry point that takes a Diffusion accepts it. */
+typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5 } tsd_model_kind;
 
 /* Parameter inventory in struct-field DFS order: `Diffusion`
  * diffusion.mojo:299-302, `Decoder` vae.mojo:194-219, `Encoder` vae.mojo:94-112.  No GPU needed. */

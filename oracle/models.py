@@ -7,7 +7,7 @@ import numpy as np
 
 from . import ops
 from .ops import DEFAULT
-from .spec import UNET_LAYERS, DECODER_LAYERS, ENCODER_LAYERS
+from .spec import UNET_LAYERS, DECODER_LAYERS, ENCODER_LAYERS, FULL_UNET_STEPS
 
 
 def _conv(P, name, x, k_pad, stride=(1, 1), pad_hw=None):
@@ -124,6 +124,38 @@ def unet(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None):
     h = ops.concat_channels(h, skip2); h = run(20, h); h = run(21, h)      # :267-269 (skip2 dead, D11)
     h = ops.concat_channels(h, skip1); h = run(22, h); h = run(23, h)      # :270-272
     return h
+
+
+def unet_full(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None):
+    """Full-size UNet (spec.FULL_UNET_STEPS; not defined by the reference): every encoder
+    output is kept as a skip, every decoder residual block reads concat(x, skip.pop()) on the channel axis."""
+    skips = []
+    h = x
+    for i, (kind, a, flags) in enumerate(FULL_UNET_STEPS, start=1):
+        name = f"{prefix}.layer{i}"
+        if flags == "pop":
+            h = ops.concat_channels(h, skips.pop())
+        if kind == "conv":
+            h = _conv(P, name, h, (1, 1), stride=(a[3], a[3]))
+        elif kind == "upconv":
+            h = _conv(P, name, ops.upsample_nearest2x(h), (1, 1))
+        elif kind == "res":
+            h = unet_residual_block(P, name, h, time, *a)
+        elif kind == "attn":
+            h = unet_attention_block(P, name, h, context, *a, sem=sem)
+        if trace is not None:
+            trace[name] = h
+        if flags == "push":
+            skips.append(h)
+    assert not skips
+    return h
+
+
+def diffusion_sd15(P, x, context, t320, sem=DEFAULT, trace=None):
+    """`Diffusion.forward` (diffusion.mojo:309-318) around the full-size UNet."""
+    time = time_embedding_mlp(P, t320)
+    h = unet_full(P, x, context, time, sem=sem, trace=trace)
+    return unet_output_layer(P, h)
 
 
 def unet_output_layer(P, x, prefix="final"):

@@ -109,6 +109,48 @@ def diffusion_params() -> List[Param]:
     return out
 
 
+# Full-size (SD-1.5-sized, 860 M parameter) UNet of BASELINE.json configs[4]: the 12-encoder / bottleneck / 12-decoder
+# layout the reference's 23-layer list was trimmed from, built from the reference's own blocks.  NOT defined by the
+# reference: parity for it is oracle-vs-product only.  (kind, args, flags): "push" = output
+# kept as a skip, "pop" = input is concat(x, most recent skip); "upconv" = nearest 2x upsample then Conv3x3.
+def _full_unet_steps():
+    R = lambda ci, co, f="": ("res", (ci, co), f)
+    A = lambda dh, f="": ("attn", (8, dh), f)
+    return [
+        ("conv", (4, 320, 3, 1), "push"),
+        R(320, 320), A(40, "push"), R(320, 320), A(40, "push"), ("conv", (320, 320, 3, 2), "push"),
+        R(320, 640), A(80, "push"), R(640, 640), A(80, "push"), ("conv", (640, 640, 3, 2), "push"),
+        R(640, 1280), A(160, "push"), R(1280, 1280), A(160, "push"), ("conv", (1280, 1280, 3, 2), "push"),
+        R(1280, 1280, "push"), R(1280, 1280, "push"),
+        R(1280, 1280), A(160), R(1280, 1280),
+        R(2560, 1280, "pop"), R(2560, 1280, "pop"), R(2560, 1280, "pop"), ("upconv", (1280, 1280, 3, 1), ""),
+        R(2560, 1280, "pop"), A(160), R(2560, 1280, "pop"), A(160), R(1920, 1280, "pop"), A(160),
+        ("upconv", (1280, 1280, 3, 1), ""),
+        R(1920, 640, "pop"), A(80), R(1280, 640, "pop"), A(80), R(960, 640, "pop"), A(80),
+        ("upconv", (640, 640, 3, 1), ""),
+        R(960, 320, "pop"), A(40), R(640, 320, "pop"), A(40), R(640, 320, "pop"), A(40),
+    ]
+
+
+FULL_UNET_STEPS = _full_unet_steps()
+
+
+def diffusion_sd15_params() -> List[Param]:
+    out: List[Param] = []
+    _lin(out, "time_embed.layer1", 320, 1280)
+    _lin(out, "time_embed.layer2", 1280, 1280)
+    for i, (kind, a, _) in enumerate(FULL_UNET_STEPS, start=1):
+        name = f"unet.layer{i}"
+        if kind in ("conv", "upconv"):
+            _conv(out, name, a[0], a[1], a[2])
+        elif kind == "res":
+            _unet_res(out, name, *a)
+        elif kind == "attn":
+            _unet_attn(out, name, *a)
+    _conv(out, "final.layer2", 320, 4, 3)
+    return out
+
+
 def _vae_res(out, name, cin, cout):  # vae.mojo:39-46
     _conv(out, name + ".conv1", cin, cout, 3)
     _conv(out, name + ".conv2", cout, cout, 3)
@@ -180,7 +222,7 @@ def clip_params() -> List[Param]:
     return out
 
 
-MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4}
+MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5}
 
 
 def tensor_id(model: str, index: int) -> int:
@@ -189,8 +231,9 @@ def tensor_id(model: str, index: int) -> int:
 
 
 def init_params(model: str, seed: int, only_used=False):
-    """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder'|'clip') -> {name: array}."""
-    plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params, "clip": clip_params}[model]()
+    """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder'|'clip'|'diffusion_sd15') -> {name: array}."""
+    plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params, "clip": clip_params,
+             "diffusion_sd15": diffusion_sd15_params}[model]()
     out = {}
     for i, p in enumerate(plist):
         if only_used and not p.used:

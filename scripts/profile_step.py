@@ -9,7 +9,7 @@ tsd.set_strict(True)
 B, L, T = int(os.environ.get("B", 8)), int(os.environ.get("L", 64)), 77
 what = os.environ.get("WHAT", "unet")
 ctx = tsd.default_context()
-d = tsd.Diffusion(seed=1234)
+d = tsd.Diffusion(seed=1234, variant=os.environ.get("VARIANT", "diffusion"))
 dec = tsd.Decoder(seed=1234) if what == "dec" else None
 lat = rng.normal(1, 1, B*4*L*L).reshape(B,4,L,L); cx = rng.normal(1, 2, B*T*768).reshape(B,T,768)
 s = tsd.Session(d.model, dec.model if dec else None, B, L, T); s.set_schedule(1000, 50, 0); s.upload(lat, cx, None, None)

@@ -36,7 +36,7 @@ int run_model(tsd_model* m, F&& fn) {
 extern "C" int tsd_diffusion_forward(tsd_model* m, const float* latents, const float* context, const float* time_emb,
                                      int B, int L, int T, float* out) {
   NOTNULL(m); NOTNULL(latents); NOTNULL(context); NOTNULL(time_emb); NOTNULL(out);
-  if (m->kind != TSD_MODEL_DIFFUSION) TSD_FAIL(TSD_E_ARG, "tsd_diffusion_forward: model is not a Diffusion");
+  if (!is_diffusion_kind(m->kind)) TSD_FAIL(TSD_E_ARG, "tsd_diffusion_forward: model is not a Diffusion");
   if (B <= 0 || B > 16 || L <= 0 || T <= 0) TSD_FAIL(TSD_E_SHAPE, "diffusion: B=%d (1..16) L=%d T=%d", B, L, T);
   tsd_ctx* ctx = m->ctx;
   return run_model(m, [&]() -> int {
@@ -162,7 +162,7 @@ static void build_schedule(tsd_session* s) {
 extern "C" int tsd_session_create(tsd_model* diffusion, tsd_model* decoder, int B, int L, int T, int cfg,
                                   tsd_session** out) {
   NOTNULL(diffusion); NOTNULL(out);
-  if (diffusion->kind != TSD_MODEL_DIFFUSION) TSD_FAIL(TSD_E_ARG, "session: first model must be a Diffusion");
+  if (!is_diffusion_kind(diffusion->kind)) TSD_FAIL(TSD_E_ARG, "session: first model must be a Diffusion");
   if (decoder && (decoder->kind != TSD_MODEL_DECODER || decoder->ctx != diffusion->ctx))
     TSD_FAIL(TSD_E_ARG, "session: decoder must be a Decoder on the same context");
   const int Bu = cfg ? 2 * B : B;

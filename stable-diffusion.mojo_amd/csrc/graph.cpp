@@ -279,8 +279,12 @@ int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act& out) {
 }
 
 // ---- `Diffusion.forward` diffusion.mojo:309-318 -------------------------------------------------------
+static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp,
+                               const float* temb, int B, int L, float* eps_out_chw);
+
 int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
                    int L, float* eps_out_chw) {
+  if (m->kind == TSD_MODEL_DIFFUSION_SD15) return g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw);
   tsd_ctx* ctx = m->ctx;
   const UNetW& u = m->unet;
   if (L % 8) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 8", L);
@@ -368,6 +372,85 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   Act hf = act_alloc(ctx, B, L, L, 320); CHECK_ALLOC(hf.p);
   TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(a[23]), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld,
                            a[23].gn_groups == 320 ? a[23].gn_part : nullptr, a[23].gn_nslab));
+  float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
+  TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
+  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));
+  return TSD_OK;
+}
+
+// Full-size UNet (TSD_MODEL_DIFFUSION_SD15, BASELINE configs[4]): the same blocks driven by the SD15_STEPS table.
+// Encoders push their output; every decoder residual block reads concat(x, popped skip) through the two-source views;
+// Upsample + conv3x3 is one implicit-GEMM launch that reads its input through the nearest-2x addressing.
+static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp,
+                               const float* temb, int B, int L, float* eps_out_chw) {
+  tsd_ctx* ctx = m->ctx;
+  const UNetW& u = m->unet;
+  if (L % 16) TSD_FAIL(TSD_E_SHAPE, "full-size UNet: latent side %d must be a multiple of 16", L);
+  float* t1 = arena_alloc<float>(ctx, (int64_t)B * 1280); CHECK_ALLOC(t1);
+  float* time = arena_alloc<float>(ctx, (int64_t)B * 1280); CHECK_ALLOC(time);
+  float* tvec = arena_alloc<float>(ctx, (int64_t)B * u.tproj.N); CHECK_ALLOC(tvec);
+  TSD_TRY(launch_small_linear(ctx, temb, B, 320, 320, u.t1.w, u.t1.Kpad, u.t1.b, 1280, 0, t1, 1280));
+  TSD_TRY(launch_small_linear(ctx, t1, B, 1280, 1280, u.t2.w, u.t2.Kpad, u.t2.b, 1280, 1, time, 1280));
+  TSD_TRY(launch_small_linear(ctx, time, B, 1280, 1280, u.tproj.w, u.tproj.Kpad, u.tproj.b, u.tproj.N, 1, tvec,
+                              u.tproj.N));
+  const int tld = u.tproj.N;
+  Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
+  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
+  // context K and V^T of all sixteen attention blocks in two GEMMs
+  const int CK = u.kproj_all.N;
+  half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
+  half_t* vtc_all = arena_alloc<half_t>(ctx, (int64_t)B * CK * Tp); CHECK_ALLOC(vtc_all);
+  {
+    GemmArgs g;
+    g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
+    g.M = B * Tp; g.N = CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
+    TSD_TRY(launch_gemm(ctx, g));
+    GemmArgs v;
+    v.A0 = u.vproj_all.w; v.lda0 = u.vproj_all.Kpad; v.sA = 0;
+    v.Wt = ctx16; v.ldw = u.vproj_all.Kpad; v.sW = (int64_t)Tp * u.vproj_all.Kpad;
+    v.M = CK; v.N = Tp; v.K = u.vproj_all.Kpad; v.batch = B;
+    v.C = vtc_all; v.ldc = Tp; v.sC = (int64_t)CK * Tp;
+    TSD_TRY(launch_gemm(ctx, v));
+  }
+  std::vector<Act> skips;
+  Act cur = x0;
+  for (int i = 0; i < SD15_N; i++) {
+    const UNetStep& st = SD15_STEPS[i];
+    const LayerDef& l = st.l;
+    // the next consumer of every layer output starts with GroupNorm(32) (the output layer's has 320 groups)
+    const int next_groups = i == SD15_N - 1 ? 320 : 32;
+    Act y;
+    if (l.kind == L_CONV) {
+      const int side = cur.H / l.d;
+      y = act_alloc_gn(ctx, B, side, side, l.b, next_groups); CHECK_ALLOC(y.p);
+      TSD_TRY(g_conv3x3(ctx, cur, u.conv[i], l.d, 1, 1, 0, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
+    } else if (l.kind == L_UPCONV) {
+      y = act_alloc_gn(ctx, B, cur.H * 2, cur.W * 2, l.b, next_groups); CHECK_ALLOC(y.p);
+      TSD_TRY(g_conv3x3(ctx, cur, u.conv[i], 1, 1, 1, 1, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
+    } else if (l.kind == L_RES) {
+      CatSrc src = cat1(cur);
+      if (st.flags & U_POP) {
+        if (skips.empty()) TSD_FAIL(TSD_E_STATE, "full-size UNet: skip stack underflow at layer %d", i + 1);
+        const Act sk = skips.back(); skips.pop_back();
+        if (sk.H != cur.H || cur.C + sk.C != l.a) TSD_FAIL(TSD_E_STATE, "full-size UNet: skip mismatch at layer %d", i + 1);
+        src = cat2(cur, sk);
+      }
+      y = act_alloc_gn(ctx, B, cur.H, cur.W, l.b, next_groups); CHECK_ALLOC(y.p);
+      TSD_TRY(g_resblock(ctx, src, B, cur.H, cur.W, 0, u.res[i], tvec, tld, y));
+    } else {  // L_ATTN
+      y = act_alloc_gn(ctx, B, cur.H, cur.W, cur.C, next_groups); CHECK_ALLOC(y.p);
+      const AttnW& w = u.attn[i];
+      CtxKV kv;
+      kv.K = kc_all + w.kv_off; kv.ldk = CK; kv.sK = (int64_t)Tp * CK;
+      kv.Vt = vtc_all + (int64_t)w.kv_off * Tp; kv.ldvt = Tp; kv.sVt = (int64_t)CK * Tp;
+      TSD_TRY(g_unet_attn(ctx, cur, w, ctx16, T, Tp, y, &kv));
+    }
+    cur = y;
+    if (st.flags & U_PUSH) skips.push_back(cur);
+  }
+  Act hf = act_alloc(ctx, B, L, L, 320); CHECK_ALLOC(hf.p);
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld,
+                           cur.gn_groups == 320 ? cur.gn_part : nullptr, cur.gn_nslab));
   float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
   TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
   TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));

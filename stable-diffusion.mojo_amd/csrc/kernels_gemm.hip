@@ -56,7 +56,7 @@ struct GemmK {
   int epi, tiles_n, xcd_n;
   float out_scale;
   float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
-  float* sk_ws; int* sk_flags; int splitk;             // split-K (2): fp32 partial tiles + one arrival flag per tile
+  float* sk_ws; int* sk_flags; int splitk; int sk_cfg;  // split-K (2/4/8 slices): fp32 partial tiles + one arrival flag per (slice, tile); host: tile cfg
 #ifdef TSD_GEMM_TS
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
 #endif
@@ -108,12 +108,14 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // tile columns, so through its private L2 it pulls 1/xcd_n of W and xcd_n/8 of A.  The host picks xcd_n to minimise
   // the fabric traffic W_bytes * (8/xcd_n) + A_bytes * xcd_n (weight-heavy M = 2048 problems want xcd_n = 8: with
   // row-only ownership every XCD re-fetched the whole 29 MB conv weight).  xcd_n = 1 is the row-only bijective remap.
-  // Split-K (p.splitk == 2, few-tile problems with a long K): the grid holds every tile twice.  The first `ntile`
-  // blocks take the SECOND half of K and hand their fp32 partial tile to the block `ntile` ids later (same XCD, so
-  // the same L2), which takes the first half, adds the partial in a fixed order and runs the epilogue.
-  const int ntile = p.splitk > 1 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
-  const int ks = p.splitk > 1 ? (blockIdx.x >= (unsigned)ntile ? 0 : 1) : 0;
-  int bid = p.splitk > 1 && ks == 0 ? (int)blockIdx.x - ntile : (int)blockIdx.x;
+  // Split-K (p.splitk = S in {2, 4, 8}, few-tile problems with a long K): the grid holds every tile S times.  Slice s
+  // owns the s-th contiguous share of K; the blocks of slices S-1 .. 1 come first in the grid and hand their fp32
+  // partial tile to the slice-0 block (the last `ntile` ids; same XCD as its producers, so the same L2), which adds
+  // the partials in slice order and runs the epilogue.
+  const int S = p.splitk;
+  const int ntile = S > 1 ? (int)gridDim.x / S : (int)gridDim.x;
+  const int ks = S > 1 ? S - 1 - (int)blockIdx.x / ntile : 0;
+  int bid = S > 1 ? (int)blockIdx.x - (S - 1 - ks) * ntile : (int)blockIdx.x;
   int tm, tn;
   if (p.xcd_n > 1) {
     const int xcd = bid & 7, idx = bid >> 3;
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   }
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk_all = p.K >> 6;
-  const int kt0 = ks ? nk_all >> 1 : 0;                                   // first K-tile of this block
-  const int nk = p.splitk > 1 ? (ks ? nk_all - (nk_all >> 1) : nk_all >> 1) : nk_all;  // and how many it owns
+  const int kt0 = S > 1 ? (ks * nk_all) / S : 0;                      // first K-tile of this block
+  const int nk = S > 1 ? ((ks + 1) * nk_all) / S - kt0 : nk_all;      // and how many it owns
   const int bz = blockIdx.y;
   const half_t* A0 = p.A0 + (long long)bz * p.sA;
   const half_t* A1 = p.A1 ? p.A1 + (long long)bz * p.sA : nullptr;
@@ -411,13 +413,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // publishes it; the consumer polls relaxed and reads the partial back with sc1 loads.  No device-scope fence
   // (`__threadfence()` = L2 write-back per producer block made split-K a net loss: 157 vs 160.5 steps/s).  Keeping the
   // pair on one XCD is only a speed choice.
-  if (p.splitk > 1) {
+  if (S > 1) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     // partial tile in the accumulator layout: (fragment, lane) -> 16 B, so every wave instruction moves 1 KiB contiguous
-    float* wsw = p.sk_ws + ((long long)(tm * p.tiles_n + tn) * NW + wave) * (FM * FN * 256);
-    const rsrc_t rws = make_rsrc(wsw, FM * FN * 1024);
-    int* flag = p.sk_flags + tm * p.tiles_n + tn;
-    if (ks) {  // producer: second half of K
+    const int tile = tm * p.tiles_n + tn;
+    if (ks) {  // producer: slot ks-1 of this tile
+      float* wsw = p.sk_ws + (((long long)(ks - 1) * ntile + tile) * NW + wave) * (FM * FN * 256);
+      const rsrc_t rws = make_rsrc(wsw, FM * FN * 1024);
       wait_vmcnt<0>();  // dead tail DMA has landed before the wave may end
 #pragma unroll
       for (int a = 0; a < FM; a++)
@@ -426,23 +428,28 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[a][b]), rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the flag
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(p.sk_flags + (ks - 1) * ntile + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    if (tid == 0) {  // consumer: bounded relaxed poll (producers have the lower block ids: always resident first)
-      int spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(4);
-      if (spins >= (1 << 18)) atomicAdd(&p.sk_flags[4095], 1);  // timed out: tsd_debug_splitk_errors() reports it
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < FM; a++)
-#pragma unroll
-      for (int b = 0; b < FN; b++) {
-        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
-        acc[a][b] += __builtin_bit_cast(f4, v);  // fixed order: first half + second half
+    for (int sl = 1; sl < S; sl++) {  // consumer: fixed order slice 0 + slice 1 + ... (bitwise reproducible)
+      int* flag = p.sk_flags + (sl - 1) * ntile + tile;
+      if (tid == 0) {  // bounded relaxed poll (producers have the lower block ids: always resident first)
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(4);
+        if (spins >= (1 << 18)) atomicAdd(&p.sk_flags[4095], 1);  // timed out: tsd_debug_splitk_errors() reports it
       }
-    if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+      __syncthreads();
+      float* wsw = p.sk_ws + (((long long)(sl - 1) * ntile + tile) * NW + wave) * (FM * FN * 256);
+      const rsrc_t rws = make_rsrc(wsw, FM * FN * 1024);
+#pragma unroll
+      for (int a = 0; a < FM; a++)
+#pragma unroll
+        for (int b = 0; b < FN; b++) {
+          const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
+          acc[a][b] += __builtin_bit_cast(f4, v);
+        }
+      if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+    }
   }
   // ---- epilogue ---------------------------------------------------------------------------
   const int g = lane >> 4;
@@ -722,7 +729,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
     if (force > 0) best = (kk.tiles_n % force == 0 && tiles_m % (8 / force) == 0) ? force : 1;
     kk.xcd_n = best;
   }
-  dim3 grid(tiles_m * kk.tiles_n * (kk.splitk > 1 ? 2 : 1), batch);
+  dim3 grid(tiles_m * kk.tiles_n * (kk.splitk > 1 ? kk.splitk : 1), batch);
   hipLaunchKernelGGL(fn, grid, dim3(WGM * WGN * 64), LDS, ctx->stream, kk);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
@@ -808,20 +815,42 @@ static bool xcd_round_robin() {
 }
 extern "C" int tsd_debug_xcd_round_robin(void) { return xcd_round_robin() ? 1 : 0; }
 
-static bool want_splitk(int M, int N, int K, int batch, int rps) {
+// Split-K plan: number of K slices (1 = none) and the tile configuration the split launch runs with.
+static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   static const int on = getenv("TSD_GEMM_SPLITK") ? atoi(getenv("TSD_GEMM_SPLITK")) : 1;
   // The decision must not depend on the batch size (bitwise batch invariance: a split changes the fp32 summation
-  // tree), so it keys on the layer: rows per sample (<= 256: the 16x16 level of a 64x64 latent), N and K.
+  // tree), so it keys on the layer: rows per sample, N and K.
+  //  * rps <= 256 (the 16x16 level of a 64x64 latent): 2 slices of 128-row tiles once K >= 4096;
+  //  * rps <= 64 (an 8x8 level: the full-size UNet's deepest at a 64x64 latent, the 23-layer graph's at 32x32): M is
+  //    a few hundred rows, so 64-row tiles and up to 8 slices - 32 tiles x 8 fill the chip where 16 tiles x 2 left
+  //    7/8 of it idle.
   static const int min_k = getenv("TSD_GEMM_SPLITK_MINK") ? atoi(getenv("TSD_GEMM_SPLITK_MINK")) : 4096;
-  if (!on || batch != 1 || N <= 16 || K < min_k || rps <= 0 || rps > 256) return false;
-  const int BN = (N % 160 == 0) ? 160 : 128;
-  const int tiles = ceil_div(M, 128) * ceil_div(N, BN);
   static const int max_tiles = getenv("TSD_GEMM_SPLITK_TILES") ? atoi(getenv("TSD_GEMM_SPLITK_TILES")) : 256;
-  return tiles <= max_tiles && tiles % 8 == 0;
+  static const int small_ways = getenv("TSD_GEMM_SPLITK_SMALL") ? atoi(getenv("TSD_GEMM_SPLITK_SMALL")) : 8;
+  if (!on || batch != 1 || N <= 16 || rps <= 0 || rps > 256) return 1;
+  const bool n160 = (N % 160 == 0);
+  const int BN = n160 ? 160 : 128;
+  int ways = 1, BM = 128;
+  if (rps <= 64 && small_ways > 1) {
+    ways = K >= 8192 ? 8 : (K >= 2048 ? 4 : (K >= 1024 ? 2 : 1));
+    if (ways > small_ways) ways = small_ways;
+    BM = 64;
+    static const int deep = getenv("TSD_GEMM_SPLITK_RING4") ? atoi(getenv("TSD_GEMM_SPLITK_RING4")) : 0;
+    if (cfg) *cfg = deep ? (n160 ? 6 : 9) : (n160 ? 7 : 10);
+  } else {
+    ways = K >= min_k ? 2 : 1;
+    if (cfg) *cfg = n160 ? 5 : 8;
+  }
+  const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  if (ways == 1 || tiles > max_tiles || tiles % 8 || (ways - 1) * tiles > 4095) return 1;
+  return ways;
 }
 static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   if (N <= 16) return 4;
-  if (want_splitk(M, N, K, batch, rps)) return (N % 160 == 0) ? 5 : 8;
+  {
+    int sk_cfg = 0;
+    if (splitk_plan(M, N, K, batch, rps, &sk_cfg) > 1) return sk_cfg;
+  }
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
   // measured on MI355X (scripts/bench_gemm.py with REAL_EPI=1, pinned issue order):
@@ -864,7 +893,7 @@ int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sa
 
 template <bool CONV>
 static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
-  const int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? ((k.N % 160 == 0) ? 5 : 8) : choose_cfg(k.M, k.N, k.K, batch, CONV));
+  const int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? k.sk_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV));
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
 
@@ -1043,10 +1072,12 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   }
   // split-K workspace (arena: the planning pass sees the same allocation) and the per-context arrival flags
   float* sk_ws = nullptr;
-  const bool splitk = g_force_cfg < 0 && want_splitk(a.M, a.N, a.K, a.batch, a.rows_per_sample_hint);
+  int sk_cfg = 0;
+  const int ways = g_force_cfg < 0 ? splitk_plan(a.M, a.N, a.K, a.batch, a.rows_per_sample_hint, &sk_cfg) : 1;
+  const bool splitk = ways > 1;
   if (splitk) {
-    const int BN = (a.N % 160 == 0) ? 160 : 128;
-    sk_ws = arena_alloc<float>(ctx, (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, BN) * 128 * BN);
+    const int BN = (a.N % 160 == 0) ? 160 : 128, BM = (sk_cfg == 7 || sk_cfg == 10 || sk_cfg == 6 || sk_cfg == 9) ? 64 : 128;
+    sk_ws = arena_alloc<float>(ctx, (int64_t)(ways - 1) * ceil_div(a.M, BM) * ceil_div(a.N, BN) * BM * BN);
     if (!sk_ws) TSD_FAIL(TSD_E_ALLOC, "gemm: split-K workspace exhausted");
   }
   if (!ctx->launch()) return TSD_OK;
@@ -1062,7 +1093,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;
-  k.splitk = splitk ? 2 : 1; k.sk_ws = sk_ws; k.sk_flags = nullptr;
+  k.splitk = splitk ? ways : 1; k.sk_cfg = sk_cfg; k.sk_ws = sk_ws; k.sk_flags = nullptr;
   if (splitk) {
     if (!ctx->sk_flags) {
       HIP_TRY(hipMalloc((void**)&ctx->sk_flags, 4096 * sizeof(int)));

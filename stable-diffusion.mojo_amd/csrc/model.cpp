@@ -16,7 +16,7 @@ static size_t packed_bytes(const ParamSpec& p) {
 
 extern "C" int tsd_model_create(tsd_ctx* ctx, int kind, tsd_model** out) {
   if (!ctx || !out) TSD_FAIL(TSD_E_ARG, "tsd_model_create: NULL argument");
-  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_CLIP) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_KIND_MAX) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
   tsd_model* m = new tsd_model();
   m->ctx = ctx;
   m->kind = kind;
@@ -168,14 +168,19 @@ LinW model_lin(const tsd_model* m, const std::string& prefix, bool use_bias) {
 }
 
 int model_resolve(tsd_model* m) {
-  if (m->kind == TSD_MODEL_DIFFUSION) {
+  if (is_diffusion_kind(m->kind)) {
     UNetW& u = m->unet;
+    const bool full = m->kind == TSD_MODEL_DIFFUSION_SD15;
+    const int n_layers = full ? SD15_N : 23;
+    u.res.assign(n_layers, ResW());
+    u.attn.assign(n_layers, AttnW());
+    u.conv.assign(n_layers, ConvW());
     u.t1 = model_lin(m, "time_embed.layer1", true);
     u.t2 = model_lin(m, "time_embed.layer2", true);
     int toff = 0, kvoff = 0;
     bool first = true;
-    for (int i = 0; i < 23; i++) {
-      const LayerDef& l = UNET_LAYERS[i];
+    for (int i = 0; i < n_layers; i++) {
+      const LayerDef& l = full ? SD15_STEPS[i].l : UNET_LAYERS[i];
       const std::string n = "unet.layer" + std::to_string(i + 1);
       if (l.kind == L_RES) {
         ResW& r = u.res[i];
@@ -203,13 +208,17 @@ int model_resolve(tsd_model* m) {
         a.kv_off = kvoff;
         if (kvoff == 0) { u.kproj_all = a.ca_k; u.vproj_all = a.ca_v; }
         kvoff += a.C;
+      } else if (full && (l.kind == L_CONV || l.kind == L_UPCONV)) {
+        u.conv[i] = model_conv(m, n);
       }
     }
-    u.tproj.N = toff;  // 6720 rows: the nine layer3 weights are contiguous in the blob
-    u.kproj_all.N = kvoff; u.vproj_all.N = kvoff;  // 6720 rows each
-    u.conv1 = model_conv(m, "unet.layer1");
-    u.conv4 = model_conv(m, "unet.layer4");
-    u.conv7 = model_conv(m, "unet.layer7");
+    u.tproj.N = toff;  // the layer3 weights of all residual blocks are contiguous in the blob (6720 rows; 20160 full-size)
+    u.kproj_all.N = kvoff; u.vproj_all.N = kvoff;  // 6720 rows each (12480 full-size)
+    if (!full) {
+      u.conv1 = model_conv(m, "unet.layer1");
+      u.conv4 = model_conv(m, "unet.layer4");
+      u.conv7 = model_conv(m, "unet.layer7");
+    }
     u.final_conv = model_conv(m, "final.layer2");
   } else if (m->kind == TSD_MODEL_CLIP) {
     ClipW& c = m->clip;

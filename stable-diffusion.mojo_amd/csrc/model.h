@@ -28,11 +28,18 @@ struct ParamSpec {
 };
 
 // layer tables (diffusion.mojo:177-201, vae.mojo:94-112,194-219)
-enum LayerKind { L_CONV, L_CONV_S2, L_RES, L_ATTN, L_UP, L_GN, L_SILU };
+enum LayerKind { L_CONV, L_CONV_S2, L_RES, L_ATTN, L_UP, L_GN, L_SILU, L_UPCONV };
 struct LayerDef { int kind; int a, b, c, d; };
 extern const LayerDef UNET_LAYERS[23];
 extern const LayerDef DECODER_LAYERS[26];
 extern const LayerDef ENCODER_LAYERS[19];
+// full-size UNet (TSD_MODEL_DIFFUSION_SD15): flat layer list with the skip-connection plumbing of each step
+enum { U_POP = 1, U_PUSH = 2 };  // input = concat(x, popped skip) ; output pushed as a skip
+struct UNetStep { LayerDef l; int flags; };
+constexpr int SD15_N = 45;
+extern const UNetStep SD15_STEPS[SD15_N];
+static inline bool is_diffusion_kind(int kind) { return kind == TSD_MODEL_DIFFUSION || kind == TSD_MODEL_DIFFUSION_SD15; }
+constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_DIFFUSION_SD15;
 
 std::vector<ParamSpec> build_param_specs(int model_kind);
 
@@ -59,8 +66,9 @@ struct UNetW {
   LinW tproj;        // concatenated layer3 of the 9 residual blocks: [6720][1280]
   LinW kproj_all, vproj_all;  // concatenated cross-attention k_proj / v_proj of the 9 attention blocks: [6720][768]
   ConvW conv1, conv4, conv7, final_conv;
-  ResW res[23];
-  AttnW attn[23];
+  std::vector<ResW> res;    // indexed by flat layer position (23 entries, or SD15_N)
+  std::vector<AttnW> attn;
+  std::vector<ConvW> conv;  // full-size UNet only: input, downsample and upsample convolutions
 };
 struct VaeW {
   std::vector<ConvW> conv;      // indexed by layer (1-based position - 1)

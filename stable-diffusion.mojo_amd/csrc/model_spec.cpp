@@ -14,6 +14,25 @@ const LayerDef UNET_LAYERS[23] = {
     {L_ATTN, 8, 80},          {L_RES, 960, 640},   {L_ATTN, 8, 80},  {L_UP},                   {L_RES, 640, 320},
     {L_ATTN, 8, 40},          {L_RES, 640, 320},   {L_ATTN, 8, 40}};
 
+// Full-size UNet: encoders push their output, every decoder block starts from concat(x, popped skip).
+#define R(ci, co, f) {{L_RES, ci, co, 0, 0}, f}
+#define A(dh, f) {{L_ATTN, 8, dh, 0, 0}, f}
+const UNetStep SD15_STEPS[SD15_N] = {
+    {{L_CONV, 4, 320, 3, 1}, U_PUSH},
+    R(320, 320, 0), A(40, U_PUSH), R(320, 320, 0), A(40, U_PUSH), {{L_CONV, 320, 320, 3, 2}, U_PUSH},
+    R(320, 640, 0), A(80, U_PUSH), R(640, 640, 0), A(80, U_PUSH), {{L_CONV, 640, 640, 3, 2}, U_PUSH},
+    R(640, 1280, 0), A(160, U_PUSH), R(1280, 1280, 0), A(160, U_PUSH), {{L_CONV, 1280, 1280, 3, 2}, U_PUSH},
+    R(1280, 1280, U_PUSH), R(1280, 1280, U_PUSH),
+    R(1280, 1280, 0), A(160, 0), R(1280, 1280, 0),  // bottleneck
+    R(2560, 1280, U_POP), R(2560, 1280, U_POP), R(2560, 1280, U_POP), {{L_UPCONV, 1280, 1280, 3, 1}, 0},
+    R(2560, 1280, U_POP), A(160, 0), R(2560, 1280, U_POP), A(160, 0), R(1920, 1280, U_POP), A(160, 0),
+    {{L_UPCONV, 1280, 1280, 3, 1}, 0},
+    R(1920, 640, U_POP), A(80, 0), R(1280, 640, U_POP), A(80, 0), R(960, 640, U_POP), A(80, 0),
+    {{L_UPCONV, 640, 640, 3, 1}, 0},
+    R(960, 320, U_POP), A(40, 0), R(640, 320, U_POP), A(40, 0), R(640, 320, U_POP), A(40, 0)};
+#undef R
+#undef A
+
 const LayerDef DECODER_LAYERS[26] = {
     {L_CONV, 4, 4, 1, 1},     {L_CONV, 4, 512, 3, 1},   {L_RES, 512, 512}, {L_ATTN, 512},     {L_RES, 512, 512},
     {L_RES, 512, 512},        {L_RES, 512, 512},        {L_RES, 512, 512}, {L_UP},            {L_CONV, 512, 512, 3, 1},
@@ -102,6 +121,17 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       else if (l.kind == L_ATTN) b.unet_attn(n, l.a, l.b);
     }
     b.conv("final.layer2", 320, 4, 3, true, true);
+  } else if (kind == TSD_MODEL_DIFFUSION_SD15) {  // same blocks, full layer list; names "unet.layerN" by flat position
+    b.lin("time_embed.layer1", 320, 1280);
+    b.lin("time_embed.layer2", 1280, 1280);
+    for (int i = 0; i < SD15_N; i++) {
+      const LayerDef& l = SD15_STEPS[i].l;
+      const std::string n = "unet.layer" + std::to_string(i + 1);
+      if (l.kind == L_CONV || l.kind == L_UPCONV) b.conv(n, l.a, l.b, l.c);
+      else if (l.kind == L_RES) b.unet_res(n, l.a, l.b);
+      else if (l.kind == L_ATTN) b.unet_attn(n, l.a, l.b);
+    }
+    b.conv("final.layer2", 320, 4, 3, true, true);
   } else if (kind == TSD_MODEL_CLIP) {  // clip.mojo:74-88 ; parameter order = oracle/spec.py clip_params()
     ParamSpec t;
     t.name = "embedding.token.weight"; t.ndim = 2; t.shape[0] = 49408; t.shape[1] = 768; t.kind = P_LIN_W;
@@ -133,13 +163,13 @@ std::vector<ParamSpec> build_param_specs(int kind) {
 }
 
 extern "C" int tsd_model_param_count(int kind) {
-  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_CLIP) return TSD_E_ARG;
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_KIND_MAX) return TSD_E_ARG;
   return (int)build_param_specs(kind).size();
 }
 
 extern "C" int tsd_model_param_info(int kind, int index, char* name, int name_cap, int64_t shape[4], int* ndim,
                                     int* used, float* init_bound) {
-  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_CLIP) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
+  if (kind < TSD_MODEL_DIFFUSION || kind > TSD_MODEL_KIND_MAX) TSD_FAIL(TSD_E_ARG, "bad model kind %d", kind);
   static thread_local int cached_kind = 0;
   static thread_local std::vector<ParamSpec> cached;
   if (cached_kind != kind) {
@@ -193,6 +223,21 @@ extern "C" double tsd_flop_count(int kind, int L, int T) {
       } else if (l.kind == L_RES) f += unet_res_f(l.a, l.b, side * side);
       else if (l.kind == L_ATTN) f += unet_attn_f((double)l.a * l.b, l.b, side * side, T);
       else if (l.kind == L_UP) side *= 2;
+    }
+    f += conv_f(320, 4, 3, (double)L * L);
+  } else if (kind == TSD_MODEL_DIFFUSION_SD15) {
+    f += lin_f(1, 320, 1280) + lin_f(1, 1280, 1280);
+    double side = L;
+    for (int i = 0; i < SD15_N; i++) {
+      const LayerDef& l = SD15_STEPS[i].l;
+      if (l.kind == L_CONV) {
+        if (l.d == 2) side /= 2;
+        f += conv_f(l.a, l.b, l.c, side * side);
+      } else if (l.kind == L_UPCONV) {
+        side *= 2;
+        f += conv_f(l.a, l.b, l.c, side * side);
+      } else if (l.kind == L_RES) f += unet_res_f(l.a, l.b, side * side);
+      else if (l.kind == L_ATTN) f += unet_attn_f((double)l.a * l.b, l.b, side * side, T);
     }
     f += conv_f(320, 4, 3, (double)L * L);
   } else if (kind == TSD_MODEL_DECODER || kind == TSD_MODEL_ENCODER) {

@@ -156,8 +156,10 @@ class Diffusion:
     forward(x, context, time): x (4,L,L) or (B,4,L,L); context (T,768)/(1,T,768) or (B,T,768);
     time = get_time_embedding(t): (1,1,320) or (B,320)."""
 
-    def __init__(self, seed=0, ctx=None, params=None):
-        self.model = Model("diffusion", ctx=ctx, seed=None if params is not None else seed)
+    def __init__(self, seed=0, ctx=None, params=None, variant="diffusion"):
+        """variant: "diffusion" (the reference's 23-layer Tiny-SD graph) or "diffusion_sd15" (full-size 860 M UNet,
+        BASELINE configs[4]; same blocks, not defined by the reference)."""
+        self.model = Model(variant, ctx=ctx, seed=None if params is not None else seed)
         if params is not None:
             self.model.load_params(params)
 

@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol(tsd_mod):
 
 def test_param_inventory_matches_oracle_spec(tsd_mod):
     for kind, plist in (("diffusion", spec.diffusion_params()), ("decoder", spec.decoder_params()),
-                        ("encoder", spec.encoder_params())):
+                        ("encoder", spec.encoder_params()), ("clip", spec.clip_params()),
+                        ("diffusion_sd15", spec.diffusion_sd15_params())):
         got = tsd_mod.param_specs(kind)
         assert len(got) == len(plist)
         for (name, shape, used, bound), p in zip(got, plist):
@@ -34,6 +35,18 @@ def test_flop_census_matches_survey(tsd_mod):
     assert abs(f("diffusion", 64) - 408.33) < 0.01 and abs(f("diffusion", 32) - 89.51) < 0.01
     assert abs(f("decoder", 64) - 2514.52) < 0.01 and abs(f("decoder", 32) - 622.19) < 0.01
     assert abs(f("encoder", 512) - 1116.66) < 0.01
+
+
+def test_full_size_unet_inventory(tsd_mod):
+    """BASELINE configs[4]: the full-size graph carries the 860 M parameters of an SD-1.5 UNet (859.3 M once the
+    per-channel norm affines the reference's GroupNorm / LayerNorm do not have are left out) and twice the work."""
+    plist = spec.diffusion_sd15_params()
+    used = sum(p.numel for p in plist if p.used)
+    assert abs(used / 1e6 - 859.32) < 0.01
+    kinds = [k for k, _, _ in spec.FULL_UNET_STEPS]
+    assert kinds.count("res") == 22 and kinds.count("attn") == 16 and kinds.count("upconv") == 3
+    assert [f for _, _, f in spec.FULL_UNET_STEPS].count("push") == [f for _, _, f in spec.FULL_UNET_STEPS].count("pop") == 12
+    assert abs(tsd_mod.flop_count("diffusion_sd15", 64) - 803.27) < 0.01
 
 
 def test_rng_twins_agree():

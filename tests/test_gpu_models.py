@@ -286,6 +286,30 @@ def test_clip_forward_matches_oracle(gpu_ctx, tsd_mod):
     clip.model.close()
 
 
+def test_full_size_unet_matches_oracle(gpu_ctx, tsd_mod):
+    """BASELINE configs[4] graph (12 encoders / bottleneck / 12 decoders, 860 M parameters) against the oracle's
+    restatement of the same graph on the same seeded weights; every skip, concat width and upsample-conv is used."""
+    d = tsd_mod.Diffusion(seed=SEED, variant="diffusion_sd15")
+    P = spec.init_params("diffusion_sd15", SEED, only_used=True)
+    B, L = 2, 16
+    lat, ctx = _inputs(B, L, tag=560)
+    temb = np.stack([ops.time_embedding(980.0), ops.time_embedding(20.0)])
+    out = d.forward(lat, ctx, temb)
+    ref = np.stack([models.diffusion_sd15(P, lat[b], ctx[b], temb[b]) for b in range(B)])
+    assert_close(out, ref, TOL_MODEL, None, "full-size Diffusion.forward L=16")
+    del P
+    # headline-size properties (batch 4 at 64x64): finite, bitwise run-to-run, batch-invariant
+    lat, ctx = _inputs(4, 64, tag=570)
+    temb = np.stack([ops.time_embedding(t) for t in (980.0, 700.0, 300.0, 0.0)])
+    a = d.forward(lat, ctx, temb)
+    b = d.forward(lat, ctx, temb)
+    assert np.isfinite(a).all() and a.std() > 1e-3
+    np.testing.assert_array_equal(a, b)
+    single = d.forward(lat[2], ctx[2], temb[2])
+    assert rel_l2(single, a[2]) < 1e-3
+    d.model.close()
+
+
 def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
     """The 16x16 level runs split-K with an in-launch hand-off (sc1 stores -> relaxed flag -> sc1 loads): after a
     headline-size forward no consumer may have timed out waiting for its partner, and the result is reproducible."""
