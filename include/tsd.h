@@ -94,6 +94,16 @@ int tsd_groupnorm_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, int gro
  * per-row normalisation of x (M,C) with the GroupNorm formula, eps = 1e-5 in the reference. */
 int tsd_layernorm_f32(tsd_ctx* ctx, const float* x, int M, int C, float eps, float* y);
 
+/* EXTENSION (not reference behaviour): the norms real, PyTorch-trained checkpoints assume -
+ * y = (x - mu) / sqrt(var + eps) * weight[c] + bias[c] (population variance, eps inside the root, per-channel affine;
+ * weight / bias may be NULL = ones / zeros), i.e. torch.nn.GroupNorm / LayerNorm.  The reference's GroupNorm has a
+ * scalar gamma, an unused beta and eps added to sigma (helpers/utils.mojo:1833-1834,1871-1873); its LayerNorm has no
+ * parameters (:2052-2061).  `silu` != 0 fuses x*sigmoid(x) after the GroupNorm. */
+int tsd_groupnorm_affine_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, int groups, float eps,
+                             const float* weight, const float* bias, int silu, float* y);
+int tsd_layernorm_affine_f32(tsd_ctx* ctx, const float* x, int M, int C, float eps, const float* weight,
+                             const float* bias, float* y);
+
 /* `SiLU.forward` helpers/utils.mojo:1892-1902 / `Gelu.forward` :1908-1919 (tanh approximation). */
 int tsd_silu_f32(tsd_ctx* ctx, const float* x, int64_t n, float* y);
 int tsd_gelu_tanh_f32(tsd_ctx* ctx, const float* x, int64_t n, float* y);

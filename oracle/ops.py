@@ -246,3 +246,35 @@ def tokens_to_chw(t, H, W):
 def rescale_to_u8_range(x):
     """pipeline.mojo:127 `images.rescale((-1,1),(0,255),clamp=True)` (helpers/utils.mojo:577-597)."""
     return np.clip((x + 1.0) * 127.5, 0.0, 255.0).astype(x.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# Extension (NOT reference behaviour, SURVEY.md section 8 f-4): the norms PyTorch-trained checkpoints assume.
+# Pinned against torch.nn.functional.group_norm / layer_norm in tests/test_oracle_pins.py.
+
+
+def group_norm_torch(x, num_groups, eps=1e-5, weight=None, bias=None):
+    """x (C,H,W): (x - mu) / sqrt(var + eps) * weight[c] + bias[c], population variance per group."""
+    C, H, W = x.shape
+    g = x.astype(np.float64).reshape(num_groups, -1)
+    mu = g.mean(axis=1, keepdims=True)
+    var = g.var(axis=1, keepdims=True)
+    y = ((g - mu) / np.sqrt(var + eps)).reshape(C, H, W)
+    if weight is not None:
+        y = y * np.asarray(weight, np.float64).reshape(C, 1, 1)
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64).reshape(C, 1, 1)
+    return y.astype(np.float32)
+
+
+def layer_norm_torch(x, eps=1e-5, weight=None, bias=None):
+    """x (M,C): per-row (x - mu) / sqrt(var + eps) * weight + bias."""
+    x64 = x.astype(np.float64)
+    mu = x64.mean(axis=-1, keepdims=True)
+    var = x64.var(axis=-1, keepdims=True)
+    y = (x64 - mu) / np.sqrt(var + eps)
+    if weight is not None:
+        y = y * np.asarray(weight, np.float64)
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64)
+    return y.astype(np.float32)

@@ -182,6 +182,50 @@ extern "C" int tsd_layernorm_f32(tsd_ctx* ctx, const float* x, int M, int C, flo
   });
 }
 
+extern "C" int tsd_groupnorm_affine_f32(tsd_ctx* ctx, const float* x, int C, int H, int W, int groups, float eps,
+                                        const float* weight, const float* bias, int silu, float* y) {
+  NOTNULL(x); NOTNULL(y);
+  if (groups <= 0 || C % groups) TSD_FAIL(TSD_E_SHAPE, "groupnorm: %d channels not divisible by %d groups", C, groups);
+  if (C % 8) TSD_FAIL(TSD_E_SHAPE, "groupnorm: C=%d must be a multiple of 8 on the device path", C);
+  return run_op(ctx, [&]() -> int {
+    Dev d{ctx};
+    float* dx = d.in(x, (int64_t)C * H * W);
+    float* dw = weight ? d.in(weight, C) : nullptr;
+    float* db = bias ? d.in(bias, C) : nullptr;
+    half_t* x16 = d.buf<half_t>((int64_t)H * W * C);
+    half_t* y16 = d.buf<half_t>((int64_t)H * W * C);
+    float* dy = d.buf<float>((int64_t)C * H * W);
+    if (d.err) return d.err;
+    TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, dx, 1, C, H, W, C, 1.f, x16, C));
+    NormSrc s; s.x0 = x16; s.ld0 = C; s.C0 = C;
+    NormAffine a; a.w = dw; a.b = db; a.torch_rstd = 1;
+    TSD_TRY(launch_groupnorm(ctx, s, 1, H * W, C, groups, eps, 1.f, silu ? 1 : 0, y16, C, nullptr, 0, &a));
+    TSD_TRY(launch_nhwc_f16_to_chw_f32(ctx, y16, 1, C, H, W, C, dy));
+    return d.out(y, dy, (int64_t)C * H * W);
+  });
+}
+
+extern "C" int tsd_layernorm_affine_f32(tsd_ctx* ctx, const float* x, int M, int C, float eps, const float* weight,
+                                        const float* bias, float* y) {
+  NOTNULL(x); NOTNULL(y);
+  if (M <= 0 || C <= 0 || C % 8) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d must be a positive multiple of 8", C);
+  return run_op(ctx, [&]() -> int {
+    Dev d{ctx};
+    float* dx = d.in(x, (int64_t)M * C);
+    float* dw = weight ? d.in(weight, C) : nullptr;
+    float* db = bias ? d.in(bias, C) : nullptr;
+    half_t* x16 = d.buf<half_t>((int64_t)M * C);
+    half_t* y16 = d.buf<half_t>((int64_t)M * C);
+    float* dy = d.buf<float>((int64_t)M * C);
+    if (d.err) return d.err;
+    TSD_TRY(launch_f32_to_f16_rows(ctx, dx, M, C, x16, C, M));
+    NormAffine a; a.w = dw; a.b = db; a.torch_rstd = 1;
+    TSD_TRY(launch_layernorm(ctx, x16, M, C, C, eps, y16, C, &a));
+    TSD_TRY(launch_f16_to_f32_rows(ctx, y16, M, C, C, dy));
+    return d.out(y, dy, (int64_t)M * C);
+  });
+}
+
 static int unary_op(tsd_ctx* ctx, int op, const float* x, int64_t n, float* y) {
   if (!x || !y) TSD_FAIL(TSD_E_ARG, "unary op: NULL argument");
   if (n <= 0) TSD_FAIL(TSD_E_SHAPE, "unary op: n=%lld", (long long)n);

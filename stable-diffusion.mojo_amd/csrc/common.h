@@ -214,9 +214,18 @@ struct NormSrc {
   const half_t* x0 = nullptr; int ld0 = 0; int C0 = 0;
   const half_t* x1 = nullptr; int ld1 = 0;
 };
+// Extension for real (PyTorch-trained) checkpoints, not reference behaviour: per-channel weight / bias and
+// 1/sqrt(var + eps) instead of the reference's 1/(sigma + eps).  nullptr = reference semantics.
+struct NormAffine {
+  const float* w = nullptr;  // [C] (nullptr: ones)
+  const float* b = nullptr;  // [C] (nullptr: zeros)
+  int torch_rstd = 1;        // 1: rsqrt(var + eps) ; 0: 1 / (sqrt(var) + eps)
+};
 int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
-                     int silu, half_t* y, int ldy, const float* pre_part = nullptr, int pre_nslab = 0);
-int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy);
+                     int silu, half_t* y, int ldy, const float* pre_part = nullptr, int pre_nslab = 0,
+                     const NormAffine* aff = nullptr);
+int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy,
+                     const NormAffine* aff = nullptr);
 
 // attention (kernels_attn.hip): fused flash attention for d_head in {40, 80, 160}.
 struct AttnArgs {

@@ -30,6 +30,7 @@ struct GnK {
   int stats_ready;  // stats[] already holds the finished (mean, scale) pairs (k_gn_finalize ran)
   half_t* y; int ldy;
   int apply_pixels;
+  const float* aw; const float* ab; int torch_rstd;  // NormAffine extension (common.h); aw == ab == nullptr && !torch_rstd: reference
 };
 
 __device__ __forceinline__ h8 gn_load(const GnK& p, int64_t pixg, int ch) {
@@ -135,7 +136,9 @@ __device__ __forceinline__ void gn_finish_groups(const GnK& p, int b, int g0, in
     double var = t2 / n - mu * mu;
     if (var < 0.0) var = 0.0;
     out[2 * g] = (float)mu;
-    out[2 * g + 1] = (float)((double)p.gamma / (sqrt(var) + (double)p.eps));  // eps added to sigma (helpers/utils.mojo:1871-1873)
+    // eps added to sigma (helpers/utils.mojo:1871-1873) ; torch_rstd (extension): eps added to the variance
+    out[2 * g + 1] = p.torch_rstd ? (float)((double)p.gamma / sqrt(var + (double)p.eps))
+                                  : (float)((double)p.gamma / (sqrt(var) + (double)p.eps));
   }
 }
 
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const GnK p) {
   gn_finish_groups(p, blockIdx.y, blockIdx.x * 32, threadIdx.x, p.stats + (int64_t)blockIdx.y * p.G * 2);
 }
 
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
   extern __shared__ __attribute__((aligned(16))) char smem_gn[];
   float* st = (float*)smem_gn;  // [G][2] (mean, gamma/(sigma+eps))
@@ -170,6 +174,19 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
       ri[q][j] = st[2 * g + 1];
     }
   }
+  float sh[AFFINE ? GN_MAX_CPT : 1][8];  // AFFINE: per-channel weight folded into ri, bias kept as a shift
+  if (AFFINE) {
+#pragma unroll
+    for (int q = 0; q < GN_MAX_CPT; q++) {
+      const int ch = m.ch0 + q * 256;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int c = ch < m.nch ? ch * 8 + j : 0;
+        if (p.aw) ri[q][j] *= p.aw[c];
+        sh[q][j] = p.ab ? p.ab[c] : 0.f;
+      }
+    }
+  }
   const int p_begin = blockIdx.x * p.apply_pixels;
   const int p_end = min(p.HW, p_begin + p.apply_pixels);
   for (int pix0 = p_begin + m.pl; pix0 < p_end; pix0 += m.PL * GN_UNROLL) {
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
               float f = ((float)v[u][j] - mu[q][j]) * ri[q][j];
+              if (AFFINE) f += sh[q][j];
               if (p.silu) f = f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));  // x*sigmoid(x): v_exp + v_rcp, no IEEE division
               o[j] = (half_t)f;
             }
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 }
 
 int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
-                     int silu, half_t* y, int ldy, const float* pre_part, int pre_nslab) {
+                     int silu, half_t* y, int ldy, const float* pre_part, int pre_nslab, const NormAffine* aff) {
   if (C % 8 || C % groups || C > 256 * 8 * GN_MAX_CPT)
     TSD_FAIL(TSD_E_SHAPE, "groupnorm: C=%d groups=%d unsupported", C, groups);
   const int C0 = src.x1 ? src.C0 : C;
@@ -223,6 +241,7 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   k.stats = arena_alloc<float>(ctx, (int64_t)B * groups * 2);
   if (!k.partial || !k.stats) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
   k.eps = eps; k.gamma = gamma; k.silu = silu; k.y = y; k.ldy = ldy;
+  k.aw = aff ? aff->w : nullptr; k.ab = aff ? aff->b : nullptr; k.torch_rstd = aff ? aff->torch_rstd : 0;
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
   if (!have_stats) {
@@ -234,16 +253,22 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
     hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);
     HIP_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
-                     ctx->stream, k);
+  if (k.aw || k.ab)
+    hipLaunchKernelGGL(k_gn_apply<true>, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
+                       ctx->stream, k);
+  else
+    hipLaunchKernelGGL(k_gn_apply<false>, dim3(ceil_div(HW, k.apply_pixels), B), dim3(256), (size_t)2 * groups * sizeof(float),
+                       ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
 
 // ---- LayerNorm over the last dim of (rows, C): one wave per row, data held in registers ----
 constexpr int LN_MAX_CH = 4;  // C <= 2048
+struct LnAff { const float* w; const float* b; int torch_rstd; };
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x, int64_t rows, int C, int ldx, float eps,
-                                                   half_t* __restrict__ y, int ldy) {
+                                                   half_t* __restrict__ y, int ldy, LnAff aff) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float r = 1.f / (sqrtf(ss / (float)C) + eps);
+  const float r = (AFFINE && aff.torch_rstd) ? rsqrtf(ss / (float)C + eps) : 1.f / (sqrtf(ss / (float)C) + eps);
   half_t* yr = y + row * ldy;
 #pragma unroll
   for (int q = 0; q < LN_MAX_CH; q++) {
@@ -285,7 +310,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
     if (ch < nch) {
       h8 o;
 #pragma unroll
-      for (int j = 0; j < 8; j++) o[j] = (half_t)(((float)v[q][j] - mu) * r);
+      for (int j = 0; j < 8; j++) {
+        float f = ((float)v[q][j] - mu) * r;
+        if (AFFINE) f = f * (aff.w ? aff.w[ch * 8 + j] : 1.f) + (aff.b ? aff.b[ch * 8 + j] : 0.f);
+        o[j] = (half_t)f;
+      }
       *(h8*)(yr + ch * 8) = o;
     }
   }
@@ -294,9 +323,9 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
 // UNet token widths (C = 40 * LPR, LPR a power of two <= 32): LPR lanes share a row, 5 chunks of 8 channels each, so a
 // wave normalises 64 / LPR rows at once with every lane busy and five independent 16-B loads in flight per lane
 // (the one-wave-per-row kernel above leaves 24 of 64 lanes idle at C = 320 and moves 640 B per wave).
-template <int LPR>
+template <int LPR, bool AFFINE>
 __global__ __launch_bounds__(256) void k_layernorm_grp(const half_t* __restrict__ x, int64_t rows, int ldx, float eps,
-                                                       half_t* __restrict__ y, int ldy) {
+                                                       half_t* __restrict__ y, int ldy, LnAff aff) {
   constexpr int RPW = 64 / LPR, C = 40 * LPR;
   const int lane = threadIdx.x & 63, sub = lane % LPR;
   const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -323,32 +352,46 @@ __global__ __launch_bounds__(256) void k_layernorm_grp(const half_t* __restrict_
     }
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float r = 1.f / (sqrtf(ss / (float)C) + eps);
+  const float r = (AFFINE && aff.torch_rstd) ? rsqrtf(ss / (float)C + eps) : 1.f / (sqrtf(ss / (float)C) + eps);
   if (!ok) return;
   half_t* yr = y + row * ldy;
 #pragma unroll
   for (int q = 0; q < 5; q++) {
     h8 o;
+    const int c0 = (sub + q * LPR) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = (half_t)(((float)v[q][j] - mu) * r);
-    *(h8*)(yr + (sub + q * LPR) * 8) = o;
+    for (int j = 0; j < 8; j++) {
+      float f = ((float)v[q][j] - mu) * r;
+      if (AFFINE) f = f * (aff.w ? aff.w[c0 + j] : 1.f) + (aff.b ? aff.b[c0 + j] : 0.f);
+      o[j] = (half_t)f;
+    }
+    *(h8*)(yr + c0) = o;
   }
 }
 
-int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy) {
-  if (C % 8 || C > 64 * 8 * LN_MAX_CH) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d unsupported", C);
-  if (!ctx->launch()) return TSD_OK;
-  ProfScope prof(ctx, KC_LAYERNORM, (int)rows, C, 0, 1);
+template <bool AFFINE>
+static void launch_layernorm_t(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy,
+                               LnAff a) {
   if (C == 320 || C == 640 || C == 1280) {
     const int lpr = C / 40, rows_per_block = 4 * (64 / lpr);
     const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
-    if (lpr == 8) hipLaunchKernelGGL(k_layernorm_grp<8>, grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy);
-    else if (lpr == 16) hipLaunchKernelGGL(k_layernorm_grp<16>, grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy);
-    else hipLaunchKernelGGL(k_layernorm_grp<32>, grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy);
+    if (lpr == 8) hipLaunchKernelGGL((k_layernorm_grp<8, AFFINE>), grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy, a);
+    else if (lpr == 16) hipLaunchKernelGGL((k_layernorm_grp<16, AFFINE>), grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy, a);
+    else hipLaunchKernelGGL((k_layernorm_grp<32, AFFINE>), grid, dim3(256), 0, ctx->stream, x, rows, ldx, eps, y, ldy, a);
   } else {
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps, y,
-                       ldy);
+    hipLaunchKernelGGL(k_layernorm<AFFINE>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, x, rows, C, ldx, eps,
+                       y, ldy, a);
   }
+}
+
+int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy,
+                     const NormAffine* aff) {
+  if (C % 8 || C > 64 * 8 * LN_MAX_CH) TSD_FAIL(TSD_E_SHAPE, "layernorm: C=%d unsupported", C);
+  if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_LAYERNORM, (int)rows, C, 0, 1);
+  LnAff a{aff ? aff->w : nullptr, aff ? aff->b : nullptr, aff ? aff->torch_rstd : 0};
+  if (aff) launch_layernorm_t<true>(ctx, x, rows, C, ldx, eps, y, ldy, a);
+  else launch_layernorm_t<false>(ctx, x, rows, C, ldx, eps, y, ldy, a);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

@@ -8,11 +8,13 @@
   tsd.clip       <-> clip.mojo              CLIP text encoder (token ids -> context)
   tsd.tokenizer  <-> helpers/utils.mojo     Tokenizer, bpe_encode (host-only logic inside libtsd)
   tsd.pipeline   <-> pipeline.mojo          generate (hot loop; the context embedding is an input)
+  tsd.ext        (no reference counterpart) torch-style GroupNorm / LayerNorm for real checkpoints
 
 Every forward() is a call through the C ABI in include/tsd.h into hand-written HIP kernels for gfx950.
 There is no CPU fallback.
 """
 from . import _lib, rng  # noqa: F401
+from . import ext  # noqa: F401  (non-reference extensions: torch-style norms)
 from ._lib import Context, TsdError, default_context, set_default_context, set_strict  # noqa: F401
 from .model import Model, Session, flop_count, param_specs  # noqa: F401
 from .utils import (Conv2D, Gelu, GroupNorm, LayerNorm, Linear, SiLU, Softmax, Upsample, concat,  # noqa: F401

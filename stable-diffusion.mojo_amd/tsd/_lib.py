@@ -64,6 +64,8 @@ def _declare(l):
         "tsd_pad_f32": ([vp, fp, i, i, i, i, i, i, i, fp], i),
         "tsd_groupnorm_f32": ([vp, fp, i, i, i, i, i, f, f, fp], i),
         "tsd_layernorm_f32": ([vp, fp, i, i, f, fp], i),
+        "tsd_groupnorm_affine_f32": ([vp, fp, i, i, i, i, f, fp, fp, i, fp], i),
+        "tsd_layernorm_affine_f32": ([vp, fp, i, i, f, fp, fp, fp], i),
         "tsd_silu_f32": ([vp, fp, i64, fp], i), "tsd_gelu_tanh_f32": ([vp, fp, i64, fp], i),
         "tsd_rescale_images_f32": ([vp, fp, i64, fp], i),
         "tsd_linear_f32": ([vp, fp, i, i, fp, fp, i, fp], i),

@@ -107,6 +107,53 @@ _gn_case("groupnorm_partial_channels", 96, 4, 5, 7, 1e-5, Cn=64)
 _gn_case("groupnorm_big_hw", 64, 32, 48, 40, 1e-5)     # several slabs
 
 
+# extension (not reference behaviour): torch-style norms for real checkpoints, pinned against torch in test_oracle_pins.py
+def _gn_torch_case(name, C, G, H, W, eps, affine=True, silu=False):
+    @case(name)
+    class _GT:
+        @staticmethod
+        def build():
+            return dict(x=randn(31, C, H, W) * 2.0 + 0.5, w=1.0 + 0.3 * randn(32, C), b=0.2 * randn(33, C))
+
+        @staticmethod
+        def oracle(i):
+            y = ops.group_norm_torch(i["x"], G, eps, i["w"] if affine else None, i["b"] if affine else None)
+            return ops.silu(y) if silu else y
+
+        @staticmethod
+        def device(tsd, i):
+            return tsd.ext.TorchGroupNorm(G, C, eps, i["w"] if affine else None, i["b"] if affine else None,
+                                          silu=silu).forward(i["x"])
+    return _GT
+
+
+_gn_torch_case("groupnorm_torch_320_32", 320, 32, 8, 8, 1e-5)
+_gn_torch_case("groupnorm_torch_silu_1280", 1280, 32, 4, 4, 1e-5, silu=True)
+_gn_torch_case("groupnorm_torch_no_affine_big_hw", 64, 32, 48, 40, 1e-6, affine=False)
+
+
+def _ln_torch_case(name, M, C, affine=True):
+    @case(name)
+    class _LT:
+        @staticmethod
+        def build():
+            return dict(x=randn(34, M, C) * 3.0 + 1.0, w=1.0 + 0.3 * randn(35, C), b=0.2 * randn(36, C))
+
+        @staticmethod
+        def oracle(i):
+            return ops.layer_norm_torch(i["x"], 1e-5, i["w"] if affine else None, i["b"] if affine else None)
+
+        @staticmethod
+        def device(tsd, i):
+            return tsd.ext.TorchLayerNorm(C, 1e-5, i["w"] if affine else None, i["b"] if affine else None).forward(i["x"])
+    return _LT
+
+
+_ln_torch_case("layernorm_torch_320", 37, 320)
+_ln_torch_case("layernorm_torch_768", 11, 768)
+_ln_torch_case("layernorm_torch_1280_no_affine", 9, 1280, affine=False)
+
+
 @case("layernorm_320")
 class _LN:
     @staticmethod

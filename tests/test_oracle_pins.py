@@ -93,6 +93,23 @@ def test_groupnorm_vs_torch_small_eps():
     np.testing.assert_allclose(y, yt, rtol=1e-3, atol=1e-4)
 
 
+def test_torch_style_norm_extension_matches_torch():
+    """The f-4 extension (per-channel affine, eps inside the root) IS torch's GroupNorm / LayerNorm."""
+    x = randn(61, 32, 5, 7) * 2.0 + 0.5
+    w, b = 1.0 + 0.3 * randn(62, 32), 0.2 * randn(63, 32)
+    for eps in (1e-5, 1e-2):
+        yt = F.group_norm(T(x)[None], 8, T(w), T(b), eps=eps)[0].numpy()
+        np.testing.assert_allclose(ops.group_norm_torch(x, 8, eps, w, b), yt, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ops.group_norm_torch(x, 8, 1e-5), F.group_norm(T(x)[None], 8, eps=1e-5)[0].numpy(),
+                               rtol=1e-5, atol=1e-5)
+    t = randn(64, 5, 16) * 3.0
+    lw, lb = 1.0 + 0.3 * randn(65, 16), 0.2 * randn(66, 16)
+    np.testing.assert_allclose(ops.layer_norm_torch(t, 1e-5, lw, lb), F.layer_norm(T(t), (16,), T(lw), T(lb), eps=1e-5).numpy(),
+                               rtol=1e-5, atol=1e-5)
+    # and it differs from the reference's formula exactly where the two put eps
+    assert not np.allclose(ops.group_norm_torch(x, 8, 1e-2), ops.group_norm(x, 8, 32, eps=1e-2), atol=1e-4)
+
+
 def test_layernorm_per_token_and_literal_global():
     x = randn(22, 5, 16)
     y = ops.layer_norm(x)
