@@ -174,8 +174,12 @@ int tsd_vae_attention_block_f32(tsd_ctx* ctx, const float* x, int C, int H, int 
  * bottleneck / 12-decoder layout the reference's 23-layer graph (diffusion.mojo:177-201) was trimmed from, built from
  * the reference's own blocks (Unet_Residual_Block diffusion.mojo:34-72, Unet_Attention_Block :87-147, Upsample
  * :149-160 followed by a 3x3 conv).  It is not defined by the reference: throughput stress configuration only; every
- * entry point that takes a Diffusion accepts it. */
-typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5 } tsd_model_kind;
+ * entry point that takes a Diffusion accepts it.
+ * TSD_MODEL_DIFFUSION_SD15_TORCH: the same graph with the norm semantics of PyTorch-trained SD-1.x checkpoints (extension,
+ * see tsd_groupnorm_affine_f32): every GroupNorm / LayerNorm carries per-channel weight and bias parameters (appended
+ * after the kind-5 parameter list as `<block>.layerN.weight` / `.bias`, N = the norm's field position in the reference
+ * struct), eps sits inside the root, and the output layer's GroupNorm has 32 groups. */
+typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5, TSD_MODEL_DIFFUSION_SD15_TORCH = 6 } tsd_model_kind;
 
 /* Parameter inventory in struct-field DFS order: `Diffusion`
  * diffusion.mojo:299-302, `Decoder` vae.mojo:194-219, `Encoder` vae.mojo:94-112.  No GPU needed. */

@@ -29,7 +29,20 @@ def time_embedding_mlp(P, t320, prefix="time_embed"):
     return _lin(P, prefix + ".layer2", h)  # (1, 1280)
 
 
-def unet_residual_block(P, prefix, x, time, cin, cout):
+def _gn(P, name, x, groups, C, eps, tn):
+    """GroupNorm of block field `name`: the reference's, or (tn) torch's with the block's weight / bias."""
+    if tn:
+        return ops.group_norm_torch(x[:C], groups, eps, P[name + ".weight"], P[name + ".bias"])
+    return ops.group_norm(x, groups, C, eps=eps)
+
+
+def _ln(P, name, x, sem, tn):
+    if tn:
+        return ops.layer_norm_torch(x, 1e-5, P[name + ".weight"], P[name + ".bias"])
+    return ops.layer_norm(x, sem=sem)
+
+
+def unet_residual_block(P, prefix, x, time, cin, cout, tn=False):
     """`Unet_Residual_Block.forward` diffusion.mojo:54-72.
 
     GN(32,cin) -> SiLU -> Conv3x3 ; + Linear(1280,cout)(SiLU(time)) broadcast over HxW (:61-65) ;
@@ -38,12 +51,12 @@ def unet_residual_block(P, prefix, x, time, cin, cout):
     """
     x = x[:cin]
     residue = x
-    h = ops.group_norm(x, 32, cin)
+    h = _gn(P, prefix + ".layer1", x, 32, cin, 1e-5, tn)
     h = ops.silu(h)
     h = _conv(P, prefix + ".layer2", h, (1, 1))
     t = _lin(P, prefix + ".layer3", ops.silu(time))          # (1, cout)
     h = h + t.reshape(cout, 1, 1)
-    h = ops.group_norm(h, 32, cout)
+    h = _gn(P, prefix + ".layer4", h, 32, cout, 1e-5, tn)
     h = ops.silu(h)
     h = _conv(P, prefix + ".layer5", h, (1, 1))
     if cin != cout:
@@ -51,7 +64,7 @@ def unet_residual_block(P, prefix, x, time, cin, cout):
     return h + residue
 
 
-def unet_attention_block(P, prefix, x, context, n_head, n_embed, sem=DEFAULT):
+def unet_attention_block(P, prefix, x, context, n_head, n_embed, sem=DEFAULT, tn=False):
     """`Unet_Attention_Block.forward` diffusion.mojo:112-147 (shape walk-through: SURVEY.md App.A.3).
 
     GN(32, eps 1e-6) -> Conv1x1 -> tokens (HW, C) -> [LN -> self-attn -> +res] ->
@@ -61,17 +74,17 @@ def unet_attention_block(P, prefix, x, context, n_head, n_embed, sem=DEFAULT):
     C = n_head * n_embed
     _, H, W = x.shape
     residue_long = x
-    h = ops.group_norm(x, 32, C, eps=1e-6)                       # :89,:116
+    h = _gn(P, prefix + ".layer1", x, 32, C, 1e-6, tn)           # :89,:116
     h = _conv(P, prefix + ".layer2", h, (0, 0))                  # :117
     tok = ops.chw_to_tokens(h)                                   # :118-120
     res = tok
-    h = ops.layer_norm(tok, sem=sem)                             # :122
+    h = _ln(P, prefix + ".layer3", tok, sem, tn)                 # :122
     h = ops.self_attention(h, n_head, P[prefix + ".layer4.in_proj.weight"], None,
                            P[prefix + ".layer4.out_proj.weight"], P[prefix + ".layer4.out_proj.bias"],
                            sem=sem)                              # :124 (in_bias=False :92)
     tok = h + res                                                # :126
     res = tok
-    h = ops.layer_norm(tok, sem=sem)                             # :129
+    h = _ln(P, prefix + ".layer5", tok, sem, tn)                 # :129
     h = ops.cross_attention(h, context, n_head,
                             P[prefix + ".layer6.q_proj.weight"], None,
                             P[prefix + ".layer6.k_proj.weight"], None,
@@ -80,7 +93,7 @@ def unet_attention_block(P, prefix, x, context, n_head, n_embed, sem=DEFAULT):
                             sem=sem)                             # :132 (in_bias=False :94)
     tok = h + res                                                # :133
     res = tok
-    h = ops.layer_norm(tok, sem=sem)                             # :136
+    h = _ln(P, prefix + ".layer7", tok, sem, tn)                 # :136
     h = _lin(P, prefix + ".layer8", h)                           # :138
     a, gate = np.split(h, 2, axis=-1)                            # chunk(2,2) :138-140
     h = a * ops.gelu_tanh(gate)                                  # :141
@@ -126,7 +139,7 @@ def unet(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None):
     return h
 
 
-def unet_full(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None):
+def unet_full(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None, tn=False):
     """Full-size UNet (spec.FULL_UNET_STEPS; not defined by the reference): every encoder
     output is kept as a skip, every decoder residual block reads concat(x, skip.pop()) on the channel axis."""
     skips = []
@@ -140,9 +153,9 @@ def unet_full(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None):
         elif kind == "upconv":
             h = _conv(P, name, ops.upsample_nearest2x(h), (1, 1))
         elif kind == "res":
-            h = unet_residual_block(P, name, h, time, *a)
+            h = unet_residual_block(P, name, h, time, *a, tn=tn)
         elif kind == "attn":
-            h = unet_attention_block(P, name, h, context, *a, sem=sem)
+            h = unet_attention_block(P, name, h, context, *a, sem=sem, tn=tn)
         if trace is not None:
             trace[name] = h
         if flags == "push":
@@ -151,10 +164,14 @@ def unet_full(P, x, context, time, sem=DEFAULT, prefix="unet", trace=None):
     return h
 
 
-def diffusion_sd15(P, x, context, t320, sem=DEFAULT, trace=None):
-    """`Diffusion.forward` (diffusion.mojo:309-318) around the full-size UNet."""
+def diffusion_sd15(P, x, context, t320, sem=DEFAULT, trace=None, tn=False):
+    """`Diffusion.forward` (diffusion.mojo:309-318) around the full-size UNet.  tn: PyTorch norm semantics (extension):
+    per-channel affine norms, eps inside the root, 32 groups in the output layer."""
     time = time_embedding_mlp(P, t320)
-    h = unet_full(P, x, context, time, sem=sem, trace=trace)
+    h = unet_full(P, x, context, time, sem=sem, trace=trace, tn=tn)
+    if tn:
+        h = ops.silu(ops.group_norm_torch(h, 32, 1e-5, P["final.layer1.weight"], P["final.layer1.bias"]))
+        return _conv(P, "final.layer2", h, (1, 1))
     return unet_output_layer(P, h)
 
 

@@ -26,6 +26,7 @@ class Param:
     kind: str        # "conv_w" | "conv_b" | "lin_w" | "lin_b"
     bound: float     # uniform init bound (0 => zeros)
     used: bool = True
+    offset: float = 0.0  # synthetic init = offset + U(+-bound)
 
     @property
     def numel(self):
@@ -151,6 +152,28 @@ def diffusion_sd15_params() -> List[Param]:
     return out
 
 
+def _norm(out, name, C):  # torch-norm extension: per-channel weight (1 + U(+-0.3)) and bias (U(+-0.2))
+    out.append(Param(name + ".weight", (C,), "lin_b", 0.3, True, 1.0))
+    out.append(Param(name + ".bias", (C,), "lin_b", 0.2))
+
+
+def diffusion_sd15_torch_params() -> List[Param]:
+    """Full-size UNet with PyTorch norm semantics (extension): the kind-5 list followed by
+    weight/bias of every GroupNorm / LayerNorm, named by the norm's field position in the reference struct."""
+    out = diffusion_sd15_params()
+    for i, (kind, a, _) in enumerate(FULL_UNET_STEPS, start=1):
+        name = f"unet.layer{i}"
+        if kind == "res":
+            _norm(out, name + ".layer1", a[0])
+            _norm(out, name + ".layer4", a[1])
+        elif kind == "attn":
+            C = a[0] * a[1]
+            for n in (1, 3, 5, 7):
+                _norm(out, f"{name}.layer{n}", C)
+    _norm(out, "final.layer1", 320)
+    return out
+
+
 def _vae_res(out, name, cin, cout):  # vae.mojo:39-46
     _conv(out, name + ".conv1", cin, cout, 3)
     _conv(out, name + ".conv2", cout, cout, 3)
@@ -222,7 +245,7 @@ def clip_params() -> List[Param]:
     return out
 
 
-MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5}
+MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5, "diffusion_sd15_torch": 6}
 
 
 def tensor_id(model: str, index: int) -> int:
@@ -233,7 +256,7 @@ def tensor_id(model: str, index: int) -> int:
 def init_params(model: str, seed: int, only_used=False):
     """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder'|'clip'|'diffusion_sd15') -> {name: array}."""
     plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params, "clip": clip_params,
-             "diffusion_sd15": diffusion_sd15_params}[model]()
+             "diffusion_sd15": diffusion_sd15_params, "diffusion_sd15_torch": diffusion_sd15_torch_params}[model]()
     out = {}
     for i, p in enumerate(plist):
         if only_used and not p.used:
@@ -241,5 +264,6 @@ def init_params(model: str, seed: int, only_used=False):
         if p.bound == 0.0:
             out[p.name] = np.zeros(p.shape, dtype=np.float32)
         else:
-            out[p.name] = rng.uniform(seed, tensor_id(model, i), p.numel, p.bound).reshape(p.shape)
+            w = rng.uniform(seed, tensor_id(model, i), p.numel, p.bound).reshape(p.shape)
+            out[p.name] = (w + np.float32(p.offset)) if p.offset else w
     return out

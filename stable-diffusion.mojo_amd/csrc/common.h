@@ -195,6 +195,7 @@ int launch_quick_gelu_f16(tsd_ctx* ctx, half_t* x, int64_t n);
 int launch_time_embedding(tsd_ctx* ctx, const float* t_dev, float t_scalar, int B, float* out);  // out [B][320]; t_dev NULL -> scalar
 int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
                         int N, int silu_in, float* y, int ldy);
+int launch_add_const_f32(tsd_ctx* ctx, float* dst, int64_t n, float c);
 int launch_fill_uniform(tsd_ctx* ctx, float* dst, int64_t n, uint64_t seed, uint64_t tensor_id, float bound);
 // weight packing: src fp32 reference layout -> packed fp16
 int launch_pack_conv(tsd_ctx* ctx, const float* src, int O, int I, int k, half_t* dst, int Opad, int Ipad);

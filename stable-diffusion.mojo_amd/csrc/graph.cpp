@@ -93,12 +93,12 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   Act h = act_alloc(ctx, B, Hin, Win, cin); CHECK_ALLOC(h.p);
   const bool x_stats = !(x.p1 && cin > x.C0) && x.gn_part0 && x.gn_groups0 == w.groups && x.C0 == cin;
   TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, 1e-5f, 1.f, 1, h.p, h.ld,
-                           x_stats ? x.gn_part0 : nullptr, x.gn_nslab0));
+                           x_stats ? x.gn_part0 : nullptr, x.gn_nslab0, w.gn1.w ? &w.gn1 : nullptr));
   Act t1 = act_alloc_gn(ctx, B, H, W, cout, w.groups); CHECK_ALLOC(t1.p);
   TSD_TRY(g_conv3x3(ctx, h, w.conv1, 1, 1, 1, ups, tvec ? tvec + w.time_off : nullptr, tld, nullptr, 0, false, t1.p, t1.ld, &t1));
   Act h3 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(h3.p);
   TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, 1e-5f, 1.f, 1, h3.p, h3.ld, t1.gn_part,
-                           t1.gn_nslab));
+                           t1.gn_nslab, w.gn2.w ? &w.gn2 : nullptr));
   Act r;
   if (w.has_skip) {  // 1x1 conv on the raw input, at the INPUT resolution (commutes with nearest upsample)
     r = act_alloc(ctx, B, Hin, Win, cout); CHECK_ALLOC(r.p);
@@ -125,7 +125,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
   const bool x_stats = x.gn_part && x.gn_groups == 32;
   TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr,
-                           x.gn_nslab));  // :89,:116
+                           x.gn_nslab, w.gn.w ? &w.gn : nullptr));  // :89,:116
   half_t* tok = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok);
   CatSrc a; a.p0 = h0; a.ld0 = C; a.C0 = C;
   TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C, nullptr, S));  // :117
@@ -136,7 +136,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   if (Sp != S) TSD_TRY(zero_async(ctx, vt, (size_t)B * C * Sp * sizeof(half_t)));  // pad keys must be finite (P = 0 there)
   half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
   // ---- self attention (:122-126) ----
-  TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C));
+  TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C, w.ln[0].w ? &w.ln[0] : nullptr));
   a.p0 = ln;
   TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C, nullptr, S));  // q,k
   {  // V^T[b] = W_v . ln_b^T  -> [B][C][S]
@@ -158,7 +158,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   a.p0 = ao;
   TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C, nullptr, S));
   // ---- cross attention (:129-133) ----
-  TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C));
+  TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C, w.ln[1].w ? &w.ln[1] : nullptr));
   half_t* q = qk;  // reuse
   a.p0 = ln;
   TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C, nullptr, S));
@@ -190,7 +190,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   a.p0 = ao;
   TSD_TRY(g_linear(ctx, a, M, w.ca_out.w, w.ca_out.Kpad, C, C, w.ca_out.b, tok2, C, 0, tok3, C, nullptr, S));
   // ---- GEGLU feed-forward (:136-143) ----
-  TSD_TRY(launch_layernorm(ctx, tok3, M, C, C, 1e-5f, ln, C));
+  TSD_TRY(launch_layernorm(ctx, tok3, M, C, C, 1e-5f, ln, C, w.ln[2].w ? &w.ln[2] : nullptr));
   half_t* gg = arena_alloc<half_t>(ctx, M * 4 * C); CHECK_ALLOC(gg);
   a.p0 = ln;
   TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S));
@@ -284,7 +284,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
 
 int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
                    int L, float* eps_out_chw) {
-  if (m->kind == TSD_MODEL_DIFFUSION_SD15) return g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw);
+  if (is_full_unet_kind(m->kind)) return g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw);
   tsd_ctx* ctx = m->ctx;
   const UNetW& u = m->unet;
   if (L % 8) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 8", L);
@@ -418,7 +418,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
     const UNetStep& st = SD15_STEPS[i];
     const LayerDef& l = st.l;
     // the next consumer of every layer output starts with GroupNorm(32) (the output layer's has 320 groups)
-    const int next_groups = i == SD15_N - 1 ? 320 : 32;
+    const int next_groups = i == SD15_N - 1 ? u.final_groups : 32;
     Act y;
     if (l.kind == L_CONV) {
       const int side = cur.H / l.d;
@@ -449,8 +449,9 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
     if (st.flags & U_PUSH) skips.push_back(cur);
   }
   Act hf = act_alloc(ctx, B, L, L, 320); CHECK_ALLOC(hf.p);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld,
-                           cur.gn_groups == 320 ? cur.gn_part : nullptr, cur.gn_nslab));
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), 320), B, L * L, 320, u.final_groups, 1e-5f, 1.f, 1, hf.p, hf.ld,
+                           cur.gn_groups == u.final_groups ? cur.gn_part : nullptr, cur.gn_nslab,
+                           u.final_gn.w ? &u.final_gn : nullptr));
   float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
   TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
   TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));

@@ -414,6 +414,16 @@ __global__ void k_fill_uniform(float* __restrict__ dst, int64_t n, uint64_t base
     dst[i] = __fmul_rn(v, bound);
   }
 }
+__global__ void k_add_const(float* __restrict__ dst, int64_t n, float c) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = __fadd_rn(dst[i], c);
+}
+int launch_add_const_f32(tsd_ctx* ctx, float* dst, int64_t n, float c) {
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_add_const, GRID1D(n, 256), dim3(256), 0, ctx->stream, dst, n, c);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
 int launch_fill_uniform(tsd_ctx* ctx, float* dst, int64_t n, uint64_t seed, uint64_t tensor_id, float bound) {
   if (!ctx->launch()) return TSD_OK;
   const uint64_t base = seed * 0x9E3779B97F4A7C15ull + tensor_id * 0xBF58476D1CE4E5B9ull;

@@ -112,6 +112,7 @@ extern "C" int tsd_model_init_random(tsd_model* m, uint64_t seed) {
     float* tmp = (float*)ctx->staging;
     if (p.bound == 0.f) HIP_TRY(hipMemsetAsync(tmp, 0, (size_t)p.numel() * sizeof(float), ctx->stream));
     else TSD_TRY(launch_fill_uniform(ctx, tmp, p.numel(), seed, (uint64_t)m->kind * 4096 + i, p.bound));
+    if (p.offset != 0.f) TSD_TRY(launch_add_const_f32(ctx, tmp, p.numel(), p.offset));
     TSD_TRY(pack_param(m, (int)i, tmp));
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -170,7 +171,17 @@ LinW model_lin(const tsd_model* m, const std::string& prefix, bool use_bias) {
 int model_resolve(tsd_model* m) {
   if (is_diffusion_kind(m->kind)) {
     UNetW& u = m->unet;
-    const bool full = m->kind == TSD_MODEL_DIFFUSION_SD15;
+    const bool full = is_full_unet_kind(m->kind);
+    const bool torch_norms = m->kind == TSD_MODEL_DIFFUSION_SD15_TORCH;
+    auto aff = [&](const std::string& name) {
+      NormAffine a;
+      if (torch_norms) {
+        a.w = (const float*)(m->blob + m->params[m->index.at(name + ".weight")].off);
+        a.b = (const float*)(m->blob + m->params[m->index.at(name + ".bias")].off);
+        a.torch_rstd = 1;
+      }
+      return a;
+    };
     const int n_layers = full ? SD15_N : 23;
     u.res.assign(n_layers, ResW());
     u.attn.assign(n_layers, AttnW());
@@ -192,6 +203,7 @@ int model_resolve(tsd_model* m) {
         r.time_off = toff;
         if (first) { u.tproj = r.time; first = false; }
         toff += l.b;
+        r.gn1 = aff(n + ".layer1"); r.gn2 = aff(n + ".layer4");
       } else if (l.kind == L_ATTN) {
         AttnW& a = u.attn[i];
         a.n_head = l.a; a.n_embed = l.b; a.C = l.a * l.b;
@@ -208,6 +220,7 @@ int model_resolve(tsd_model* m) {
         a.kv_off = kvoff;
         if (kvoff == 0) { u.kproj_all = a.ca_k; u.vproj_all = a.ca_v; }
         kvoff += a.C;
+        a.gn = aff(n + ".layer1"); a.ln[0] = aff(n + ".layer3"); a.ln[1] = aff(n + ".layer5"); a.ln[2] = aff(n + ".layer7");
       } else if (full && (l.kind == L_CONV || l.kind == L_UPCONV)) {
         u.conv[i] = model_conv(m, n);
       }
@@ -220,6 +233,8 @@ int model_resolve(tsd_model* m) {
       u.conv7 = model_conv(m, "unet.layer7");
     }
     u.final_conv = model_conv(m, "final.layer2");
+    u.final_gn = aff("final.layer1");
+    u.final_groups = torch_norms ? 32 : 320;
   } else if (m->kind == TSD_MODEL_CLIP) {
     ClipW& c = m->clip;
     c.tok = (const half_t*)(m->blob + m->params[m->index.at("embedding.token.weight")].off);

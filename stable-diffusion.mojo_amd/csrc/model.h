@@ -15,6 +15,7 @@ struct ParamSpec {
   int kind = 0;
   bool used = true;
   float bound = 0.f;  // synthetic-init bound (0 -> zeros)
+  float offset = 0.f; // synthetic init = offset + U(+-bound) (norm weights: 1 + ...)
   // packing
   int Opad = 0, Kpad = 0;  // conv: Opad rows, Kpad = Ipad ; linear: Kpad
   int interleave = 0;      // GEGLU (a,g) row interleave (diffusion.mojo:138-141)
@@ -38,8 +39,9 @@ enum { U_POP = 1, U_PUSH = 2 };  // input = concat(x, popped skip) ; output push
 struct UNetStep { LayerDef l; int flags; };
 constexpr int SD15_N = 45;
 extern const UNetStep SD15_STEPS[SD15_N];
-static inline bool is_diffusion_kind(int kind) { return kind == TSD_MODEL_DIFFUSION || kind == TSD_MODEL_DIFFUSION_SD15; }
-constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_DIFFUSION_SD15;
+static inline bool is_full_unet_kind(int kind) { return kind == TSD_MODEL_DIFFUSION_SD15 || kind == TSD_MODEL_DIFFUSION_SD15_TORCH; }
+static inline bool is_diffusion_kind(int kind) { return kind == TSD_MODEL_DIFFUSION || is_full_unet_kind(kind); }
+constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_DIFFUSION_SD15_TORCH;
 
 std::vector<ParamSpec> build_param_specs(int model_kind);
 
@@ -49,12 +51,14 @@ struct ResW {
   int cin = 0, cout = 0, groups = 32;
   bool has_skip = false;
   int time_off = 0;  // column offset into the concatenated time projection [B][6720]
+  NormAffine gn1, gn2;  // torch-norm extension (kind 6): per-channel affine of the two GroupNorms (w == nullptr: reference)
 };
 struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   int n_head = 0, n_embed = 0, C = 0, d_ctx = 768;
   ConvW conv_in, conv_out;
   LinW sa_in, sa_out, ca_q, ca_k, ca_v, ca_out, geglu1, geglu2;
   int kv_off = 0;  // row offset of this block in the concatenated k_proj / v_proj tables
+  NormAffine gn, ln[3];  // torch-norm extension (kind 6)
 };
 struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;
@@ -69,6 +73,8 @@ struct UNetW {
   std::vector<ResW> res;    // indexed by flat layer position (23 entries, or SD15_N)
   std::vector<AttnW> attn;
   std::vector<ConvW> conv;  // full-size UNet only: input, downsample and upsample convolutions
+  NormAffine final_gn;      // torch-norm extension (kind 6)
+  int final_groups = 320;   // UNet_Output_Layer's GroupNorm (diffusion.mojo:287-291); 32 with torch norms
 };
 struct VaeW {
   std::vector<ConvW> conv;      // indexed by layer (1-based position - 1)

@@ -77,6 +77,14 @@ struct Builder {
     b.bound = w.bound; b.Opad = fout; b.interleave = interleave; b.region = region == 1 ? 2 : 0;
     out.push_back(b);
   }
+  void norm(const std::string& name, int C) {  // torch-norm extension: per-channel weight (1 + U) and bias
+    ParamSpec w;
+    w.name = name + ".weight"; w.ndim = 1; w.shape[0] = C; w.kind = P_LIN_B; w.bound = 0.3f; w.offset = 1.f; w.Opad = C;
+    out.push_back(w);
+    ParamSpec b;
+    b.name = name + ".bias"; b.ndim = 1; b.shape[0] = C; b.kind = P_LIN_B; b.bound = 0.2f; b.Opad = C;
+    out.push_back(b);
+  }
   void unet_res(const std::string& n, int cin, int cout) {  // diffusion.mojo:34-42
     conv(n + ".layer2", cin, cout, 3);
     lin(n + ".layer3", 1280, cout, true, true, 0, 1);
@@ -121,7 +129,7 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       else if (l.kind == L_ATTN) b.unet_attn(n, l.a, l.b);
     }
     b.conv("final.layer2", 320, 4, 3, true, true);
-  } else if (kind == TSD_MODEL_DIFFUSION_SD15) {  // same blocks, full layer list; names "unet.layerN" by flat position
+  } else if (is_full_unet_kind(kind)) {  // same blocks, full layer list; names "unet.layerN" by flat position
     b.lin("time_embed.layer1", 320, 1280);
     b.lin("time_embed.layer2", 1280, 1280);
     for (int i = 0; i < SD15_N; i++) {
@@ -132,6 +140,18 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       else if (l.kind == L_ATTN) b.unet_attn(n, l.a, l.b);
     }
     b.conv("final.layer2", 320, 4, 3, true, true);
+    if (kind == TSD_MODEL_DIFFUSION_SD15_TORCH) {  // norm parameters appended, so the shared indices equal kind 5's
+      for (int i = 0; i < SD15_N; i++) {
+        const LayerDef& l = SD15_STEPS[i].l;
+        const std::string n = "unet.layer" + std::to_string(i + 1);
+        if (l.kind == L_RES) { b.norm(n + ".layer1", l.a); b.norm(n + ".layer4", l.b); }
+        else if (l.kind == L_ATTN) {
+          const int C = l.a * l.b;
+          b.norm(n + ".layer1", C); b.norm(n + ".layer3", C); b.norm(n + ".layer5", C); b.norm(n + ".layer7", C);
+        }
+      }
+      b.norm("final.layer1", 320);
+    }
   } else if (kind == TSD_MODEL_CLIP) {  // clip.mojo:74-88 ; parameter order = oracle/spec.py clip_params()
     ParamSpec t;
     t.name = "embedding.token.weight"; t.ndim = 2; t.shape[0] = 49408; t.shape[1] = 768; t.kind = P_LIN_W;
@@ -225,7 +245,7 @@ extern "C" double tsd_flop_count(int kind, int L, int T) {
       else if (l.kind == L_UP) side *= 2;
     }
     f += conv_f(320, 4, 3, (double)L * L);
-  } else if (kind == TSD_MODEL_DIFFUSION_SD15) {
+  } else if (is_full_unet_kind(kind)) {
     f += lin_f(1, 320, 1280) + lin_f(1, 1280, 1280);
     double side = L;
     for (int i = 0; i < SD15_N; i++) {

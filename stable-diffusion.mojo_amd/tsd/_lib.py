@@ -19,7 +19,7 @@ TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE 
 # libtsd.so (or torch, in the multi-GPU bench) makes the process's first HIP call.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
-MODEL_DIFFUSION, MODEL_DECODER, MODEL_ENCODER, MODEL_CLIP, MODEL_DIFFUSION_SD15 = 1, 2, 3, 4, 5
+MODEL_DIFFUSION, MODEL_DECODER, MODEL_ENCODER, MODEL_CLIP, MODEL_DIFFUSION_SD15, MODEL_DIFFUSION_SD15_TORCH = 1, 2, 3, 4, 5, 6
 
 
 class TsdError(RuntimeError):

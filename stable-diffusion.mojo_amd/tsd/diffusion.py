@@ -158,7 +158,8 @@ class Diffusion:
 
     def __init__(self, seed=0, ctx=None, params=None, variant="diffusion"):
         """variant: "diffusion" (the reference's 23-layer Tiny-SD graph) or "diffusion_sd15" (full-size 860 M UNet,
-        BASELINE configs[4]; same blocks, not defined by the reference)."""
+        BASELINE configs[4]; same blocks, not defined by the reference) or "diffusion_sd15_torch" (that graph with the
+        norm semantics and parameters of PyTorch-trained SD-1.x checkpoints, see tsd.checkpoint)."""
         self.model = Model(variant, ctx=ctx, seed=None if params is not None else seed)
         if params is not None:
             self.model.load_params(params)

@@ -310,6 +310,28 @@ def test_full_size_unet_matches_oracle(gpu_ctx, tsd_mod):
     d.model.close()
 
 
+def test_torch_norm_unet_and_checkpoint_import(gpu_ctx, tsd_mod):
+    """Extension (f-4): the full-size graph with PyTorch norm semantics against the oracle's torch-style restatement, and
+    a model loaded through the diffusers key map equals the directly initialised one bit for bit."""
+    from tsd import checkpoint as ck
+    d = tsd_mod.Diffusion(seed=SEED, variant="diffusion_sd15_torch")
+    P = spec.init_params("diffusion_sd15_torch", SEED)
+    B, L = 2, 16
+    lat, ctx = _inputs(B, L, tag=580)
+    temb = np.stack([ops.time_embedding(980.0), ops.time_embedding(20.0)])
+    out = d.forward(lat, ctx, temb)
+    ref = np.stack([models.diffusion_sd15(P, lat[b], ctx[b], temb[b], tn=True) for b in range(B)])
+    assert_close(out, ref, TOL_MODEL, None, "full-size Diffusion.forward, torch norms, L=16")
+    plain = np.stack([models.diffusion_sd15(P, lat[b], ctx[b], temb[b]) for b in range(B)])
+    assert rel_l2(plain, ref) > 0.05  # the two semantics really differ on these weights
+    sd = ck.params_to_diffusers_sd15_unet(P)           # what a checkpoint file would hold (686 tensors)
+    other = tsd_mod.Diffusion(params={**{n: np.zeros(s, np.float32) for n, s, u, _ in tsd_mod.param_specs("diffusion_sd15_torch") if not u},
+                                      **ck.diffusers_sd15_unet_to_params(sd)}, variant="diffusion_sd15_torch")
+    np.testing.assert_array_equal(other.forward(lat, ctx, temb), out)
+    other.model.close()
+    d.model.close()
+
+
 def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
     """The 16x16 level runs split-K with an in-launch hand-off (sc1 stores -> relaxed flag -> sc1 loads): after a
     headline-size forward no consumer may have timed out waiting for its partner, and the result is reproducible."""
