@@ -229,3 +229,44 @@ def test_clip_parameter_census_and_padding():
     np.testing.assert_allclose(a[:3], c[:3], rtol=1e-5, atol=1e-6)
     # per-token LayerNorm with no affine at the end: zero mean over channels
     np.testing.assert_allclose(a.mean(axis=-1), 0.0, atol=1e-4)
+
+
+def test_clip_graph_matches_transformers_cliptextmodel():
+    """Independent pin of the CLIP text encoder (f-3): the oracle's intended-semantics graph (clip.mojo:36-109) against
+    Hugging Face's CLIPTextModel - the architecture clip.mojo was written from - on the same random weights: token +
+    position embedding, 12 pre-LN layers with causal 12-head attention and quick-GELU, final LayerNorm.  The model's
+    LayerNorm weights stay (1, 0) (the reference's LayerNorm has no parameters) and activations are O(1), so where the
+    two put eps (sigma + eps vs sqrt(var + eps)) moves the result by ~1e-5 only."""
+    tr = pytest.importorskip("transformers")
+    torch.manual_seed(0)
+    cfg = tr.CLIPTextConfig(vocab_size=1000, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                            num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                            eos_token_id=999, bos_token_id=998, pad_token_id=0)
+    m = tr.CLIPTextModel(cfg).eval()
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if "layer_norm" in k:
+                continue
+            if "embedding" in k:
+                v.normal_(0, 1.0)
+            elif k.endswith("weight"):
+                v.normal_(0, 1.0 / np.sqrt(v.shape[1]))
+            else:
+                v.normal_(0, 0.1)
+    pre = "text_model." if any(k.startswith("text_model.") for k in sd) else ""
+    g = lambda k: sd[pre + k].numpy()  # noqa: E731
+    P = {"embedding.token.weight": g("embeddings.token_embedding.weight"),
+         "embedding.position": g("embeddings.position_embedding.weight").reshape(-1)}
+    for i in range(12):
+        h, n = f"encoder.layers.{i}.", f"player{i + 1}"
+        P[n + ".layer2.in_proj.weight"] = np.concatenate([g(h + f"self_attn.{x}_proj.weight") for x in "qkv"])
+        P[n + ".layer2.in_proj.bias"] = np.concatenate([g(h + f"self_attn.{x}_proj.bias") for x in "qkv"])
+        P[n + ".layer2.out_proj.weight"], P[n + ".layer2.out_proj.bias"] = g(h + "self_attn.out_proj.weight"), g(h + "self_attn.out_proj.bias")
+        P[n + ".layer4.weight"], P[n + ".layer4.bias"] = g(h + "mlp.fc1.weight"), g(h + "mlp.fc1.bias")
+        P[n + ".layer5.weight"], P[n + ".layer5.bias"] = g(h + "mlp.fc2.weight"), g(h + "mlp.fc2.bias")
+    tok = np.random.RandomState(1).randint(1, 998, size=77)
+    with torch.no_grad():
+        ref = m(input_ids=torch.from_numpy(tok)[None]).last_hidden_state[0].numpy()
+    y = models.clip(P, tok)
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 1e-4
