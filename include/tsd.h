@@ -178,8 +178,11 @@ int tsd_vae_attention_block_f32(tsd_ctx* ctx, const float* x, int C, int H, int 
  * TSD_MODEL_DIFFUSION_SD15_TORCH: the same graph with the norm semantics of PyTorch-trained SD-1.x checkpoints (extension,
  * see tsd_groupnorm_affine_f32): every GroupNorm / LayerNorm carries per-channel weight and bias parameters (appended
  * after the kind-5 parameter list as `<block>.layerN.weight` / `.bias`, N = the norm's field position in the reference
- * struct), eps sits inside the root, and the output layer's GroupNorm has 32 groups. */
-typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5, TSD_MODEL_DIFFUSION_SD15_TORCH = 6 } tsd_model_kind;
+ * struct), eps sits inside the root, and the output layer's GroupNorm has 32 groups.
+ * TSD_MODEL_CLIP_TORCH: the CLIP text encoder (clip.mojo:74-109) with torch LayerNorms - weight and bias of the two
+ * LayerNorms of every layer (`playerN.layer1`, `playerN.layer3`) and of the final one (`layernorm`) appended to the
+ * kind-4 parameter list; this is exactly Hugging Face's CLIPTextModel (the ViT-L/14 text tower SD-1.x conditions on). */
+typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5, TSD_MODEL_DIFFUSION_SD15_TORCH = 6, TSD_MODEL_CLIP_TORCH = 7 } tsd_model_kind;
 
 /* Parameter inventory in struct-field DFS order: `Diffusion`
  * diffusion.mojo:299-302, `Decoder` vae.mojo:194-219, `Encoder` vae.mojo:94-112.  No GPU needed. */

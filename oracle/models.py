@@ -259,27 +259,27 @@ def encoder(P, x, noise, sem=DEFAULT, trace=None):
 # ---------------------------------------------------------------------------------------------
 # clip.mojo (the step before the hot path; intended semantics only, App.A D3/D8/D15/D20)
 
-def clip_layer(P, prefix, x, n_head=12, sem=DEFAULT):
+def clip_layer(P, prefix, x, n_head=12, sem=DEFAULT, tn=False):
     """`ClipPlayer.forward` clip.mojo:36-53: LN -> causal self-attention -> +res -> LN -> Linear -> quick-GELU -> Linear -> +res."""
     res = x
-    h = ops.layer_norm(x, sem=sem)
+    h = _ln(P, prefix + ".layer1", x, sem, tn)
     h = ops.self_attention(h, n_head, P[prefix + ".layer2.in_proj.weight"], P[prefix + ".layer2.in_proj.bias"],
                            P[prefix + ".layer2.out_proj.weight"], P[prefix + ".layer2.out_proj.bias"], causal=True, sem=sem)
     x = h + res
     res = x
-    h = ops.layer_norm(x, sem=sem)
+    h = _ln(P, prefix + ".layer3", x, sem, tn)
     h = _lin(P, prefix + ".layer4", h)
     h = ops.quick_gelu(h)
     h = _lin(P, prefix + ".layer5", h)
     return h + res
 
 
-def clip(P, tokens, sem=DEFAULT, n_token=77):
+def clip(P, tokens, sem=DEFAULT, n_token=77, tn=False):
     """`CLIP.forward` clip.mojo:90-109: token ids (<= 77, zero-padded to 77 like :91-93) -> (77, 768)."""
     t = np.zeros(n_token, dtype=np.int64)
     tokens = np.asarray(tokens, dtype=np.int64).reshape(-1)
     t[: len(tokens)] = tokens
     x = ops.embedding(t, P["embedding.token.weight"]) + P["embedding.position"].reshape(n_token, -1)  # clip.mojo:17-20
     for i in range(1, 13):
-        x = clip_layer(P, f"player{i}", x, sem=sem)
-    return ops.layer_norm(x, sem=sem)
+        x = clip_layer(P, f"player{i}", x, sem=sem, tn=tn)
+    return _ln(P, "layernorm", x, sem, tn)

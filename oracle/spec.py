@@ -245,7 +245,17 @@ def clip_params() -> List[Param]:
     return out
 
 
-MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5, "diffusion_sd15_torch": 6}
+def clip_torch_params() -> List[Param]:
+    """CLIP text encoder with torch LayerNorms (extension): the kind-4 list + weight/bias of every LayerNorm."""
+    out = clip_params()
+    for i in range(1, 13):
+        _norm(out, f"player{i}.layer1", 768)
+        _norm(out, f"player{i}.layer3", 768)
+    _norm(out, "layernorm", 768)
+    return out
+
+
+MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5, "diffusion_sd15_torch": 6, "clip_torch": 7}
 
 
 def tensor_id(model: str, index: int) -> int:
@@ -256,7 +266,7 @@ def tensor_id(model: str, index: int) -> int:
 def init_params(model: str, seed: int, only_used=False):
     """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder'|'clip'|'diffusion_sd15') -> {name: array}."""
     plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params, "clip": clip_params,
-             "diffusion_sd15": diffusion_sd15_params, "diffusion_sd15_torch": diffusion_sd15_torch_params}[model]()
+             "diffusion_sd15": diffusion_sd15_params, "diffusion_sd15_torch": diffusion_sd15_torch_params, "clip_torch": clip_torch_params}[model]()
     out = {}
     for i, p in enumerate(plist):
         if only_used and not p.used:

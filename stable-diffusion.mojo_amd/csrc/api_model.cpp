@@ -96,7 +96,7 @@ extern "C" int tsd_encoder_forward(tsd_model* m, const float* images, const floa
 
 extern "C" int tsd_clip_forward(tsd_model* m, const int32_t* tokens, int B, int T, float* context) {
   NOTNULL(m); NOTNULL(tokens); NOTNULL(context);
-  if (m->kind != TSD_MODEL_CLIP) TSD_FAIL(TSD_E_ARG, "tsd_clip_forward: model is not a CLIP");
+  if (!is_clip_kind(m->kind)) TSD_FAIL(TSD_E_ARG, "tsd_clip_forward: model is not a CLIP");
   if (B <= 0 || T <= 0 || T > 77) TSD_FAIL(TSD_E_SHAPE, "clip: B=%d T=%d (1..77 tokens)", B, T);
   tsd_ctx* ctx = m->ctx;
   std::vector<int32_t> padded((size_t)B * 77, 0);  // clip.mojo:91-93: a zero row of 77 ids, the prompt's ids in front

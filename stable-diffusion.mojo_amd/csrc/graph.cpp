@@ -587,7 +587,7 @@ int g_clip_forward(tsd_model* m, const int* tokens_dev, int B, float* out_f32) {
   for (int l = 0; l < 12; l++) {
     const ClipLayerW& w = c.layer[l];
     // ---- LN -> causal self-attention -> + residue (clip.mojo:37-43) ----
-    TSD_TRY(launch_layernorm(ctx, x, M, D, D, 1e-5f, ln, D));
+    TSD_TRY(launch_layernorm(ctx, x, M, D, D, 1e-5f, ln, D, w.ln1.w ? &w.ln1 : nullptr));
     a.p0 = ln; a.ld0 = D; a.C0 = D;
     TSD_TRY(g_linear(ctx, a, M, w.in_proj.w, w.in_proj.Kpad, 2 * D, D, w.in_proj.b, nullptr, 0, 0, qk, 2 * D));  // q, k
     {  // V^T[b] = W_v . ln_b^T + b_v  -> [B][768][128]
@@ -618,13 +618,13 @@ int g_clip_forward(tsd_model* m, const int* tokens_dev, int B, float* out_f32) {
     a.p0 = ao; a.ld0 = D; a.C0 = D;
     TSD_TRY(g_linear(ctx, a, M, w.out_proj.w, w.out_proj.Kpad, D, D, w.out_proj.b, x, D, 0, x2, D));
     // ---- LN -> Linear -> quick-GELU -> Linear -> + residue (clip.mojo:44-53) ----
-    TSD_TRY(launch_layernorm(ctx, x2, M, D, D, 1e-5f, ln, D));
+    TSD_TRY(launch_layernorm(ctx, x2, M, D, D, 1e-5f, ln, D, w.ln2.w ? &w.ln2 : nullptr));
     a.p0 = ln;
     TSD_TRY(g_linear(ctx, a, M, w.l4.w, w.l4.Kpad, 4 * D, D, w.l4.b, nullptr, 0, 0, ff, 4 * D));
     TSD_TRY(launch_quick_gelu_f16(ctx, ff, M * 4 * D));
     a.p0 = ff; a.ld0 = 4 * D; a.C0 = 4 * D;
     TSD_TRY(g_linear(ctx, a, M, w.l5.w, w.l5.Kpad, D, 4 * D, w.l5.b, x2, D, 0, x, D));
   }
-  TSD_TRY(launch_layernorm(ctx, x, M, D, D, 1e-5f, ln, D));  // clip.mojo:106-108
+  TSD_TRY(launch_layernorm(ctx, x, M, D, D, 1e-5f, ln, D, c.final_ln.w ? &c.final_ln : nullptr));  // clip.mojo:106-108
   return launch_f16_to_f32_rows(ctx, ln, M, D, D, out_f32);
 }

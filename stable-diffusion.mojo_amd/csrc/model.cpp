@@ -235,8 +235,18 @@ int model_resolve(tsd_model* m) {
     u.final_conv = model_conv(m, "final.layer2");
     u.final_gn = aff("final.layer1");
     u.final_groups = torch_norms ? 32 : 320;
-  } else if (m->kind == TSD_MODEL_CLIP) {
+  } else if (is_clip_kind(m->kind)) {
     ClipW& c = m->clip;
+    auto aff = [&](const std::string& name) {
+      NormAffine a;
+      if (m->kind == TSD_MODEL_CLIP_TORCH) {
+        a.w = (const float*)(m->blob + m->params[m->index.at(name + ".weight")].off);
+        a.b = (const float*)(m->blob + m->params[m->index.at(name + ".bias")].off);
+        a.torch_rstd = 1;
+      }
+      return a;
+    };
+    c.final_ln = aff("layernorm");
     c.tok = (const half_t*)(m->blob + m->params[m->index.at("embedding.token.weight")].off);
     c.pos = (const float*)(m->blob + m->params[m->index.at("embedding.position")].off);
     for (int i = 0; i < 12; i++) {
@@ -245,6 +255,8 @@ int model_resolve(tsd_model* m) {
       c.layer[i].out_proj = model_lin(m, n + ".layer2.out_proj", true);
       c.layer[i].l4 = model_lin(m, n + ".layer4", true);
       c.layer[i].l5 = model_lin(m, n + ".layer5", true);
+      c.layer[i].ln1 = aff(n + ".layer1");
+      c.layer[i].ln2 = aff(n + ".layer3");
     }
   } else {
     const LayerDef* L = m->kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;

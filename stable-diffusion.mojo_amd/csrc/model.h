@@ -41,7 +41,8 @@ constexpr int SD15_N = 45;
 extern const UNetStep SD15_STEPS[SD15_N];
 static inline bool is_full_unet_kind(int kind) { return kind == TSD_MODEL_DIFFUSION_SD15 || kind == TSD_MODEL_DIFFUSION_SD15_TORCH; }
 static inline bool is_diffusion_kind(int kind) { return kind == TSD_MODEL_DIFFUSION || is_full_unet_kind(kind); }
-constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_DIFFUSION_SD15_TORCH;
+static inline bool is_clip_kind(int kind) { return kind == TSD_MODEL_CLIP || kind == TSD_MODEL_CLIP_TORCH; }
+constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_CLIP_TORCH;
 
 std::vector<ParamSpec> build_param_specs(int model_kind);
 
@@ -82,11 +83,12 @@ struct VaeW {
   std::vector<VaeAttnW> attn;
 };
 
-struct ClipLayerW { LinW in_proj, out_proj, l4, l5; };  // ClipPlayer clip.mojo:23-34 (its LayerNorms have no parameters)
+struct ClipLayerW { LinW in_proj, out_proj, l4, l5; NormAffine ln1, ln2; };  // ClipPlayer clip.mojo:23-34 (its LayerNorms have no parameters)
 struct ClipW {
   const half_t* tok = nullptr;  // [49408][768] fp16
   const float* pos = nullptr;   // [77][768] fp32
   ClipLayerW layer[12];
+  NormAffine final_ln;  // torch-norm extension (kind 7)
 };
 
 struct PlanKey { int B, L, T; bool operator<(const PlanKey& o) const { return B != o.B ? B < o.B : (L != o.L ? L < o.L : T < o.T); } };

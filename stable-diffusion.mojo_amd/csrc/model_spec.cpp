@@ -152,7 +152,7 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       }
       b.norm("final.layer1", 320);
     }
-  } else if (kind == TSD_MODEL_CLIP) {  // clip.mojo:74-88 ; parameter order = oracle/spec.py clip_params()
+  } else if (is_clip_kind(kind)) {  // clip.mojo:74-88 ; parameter order = oracle/spec.py clip_params()
     ParamSpec t;
     t.name = "embedding.token.weight"; t.ndim = 2; t.shape[0] = 49408; t.shape[1] = 768; t.kind = P_LIN_W;
     t.bound = 1.7320508075688772f;  // unit variance like init_weights_normal(0,1), helpers/utils.mojo:2025
@@ -167,6 +167,13 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       b.lin(n + ".layer2.out_proj", 768, 768);
       b.lin(n + ".layer4", 768, 4 * 768);
       b.lin(n + ".layer5", 4 * 768, 768);
+    }
+    if (kind == TSD_MODEL_CLIP_TORCH) {
+      for (int i = 1; i <= 12; i++) {
+        b.norm("player" + std::to_string(i) + ".layer1", 768);
+        b.norm("player" + std::to_string(i) + ".layer3", 768);
+      }
+      b.norm("layernorm", 768);
     }
   } else if (kind == TSD_MODEL_DECODER || kind == TSD_MODEL_ENCODER) {
     const LayerDef* L = kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
@@ -272,7 +279,7 @@ extern "C" double tsd_flop_count(int kind, int L, int T) {
       else if (l.kind == L_ATTN) f += vae_attn_f(l.a, side * side);
       else if (l.kind == L_UP) side *= 2;
     }
-  } else if (kind == TSD_MODEL_CLIP) {  // per prompt: 12 x (in_proj, QK^T, PV, out_proj, 768->3072->768) on 77 tokens
+  } else if (is_clip_kind(kind)) {  // per prompt: 12 x (in_proj, QK^T, PV, out_proj, 768->3072->768) on 77 tokens
     const double Tc = 77, D = 768;
     f = 12.0 * (lin_f(Tc, D, 3 * D) + 2.0 * 2.0 * Tc * Tc * D + lin_f(Tc, D, D) + lin_f(Tc, D, 4 * D) + lin_f(Tc, 4 * D, D));
   } else {

@@ -183,3 +183,33 @@ def load_sd15_unet(path, ctx=None, prefix=""):
         elif tuple(params[name].shape) != tuple(shape):
             raise ValueError(f"{name}: checkpoint shape {params[name].shape}, model expects {shape}")
     return Diffusion(ctx=ctx, params=params, variant="diffusion_sd15_torch")
+
+
+def hf_clip_text_to_params(state):
+    """Hugging Face CLIPTextModel state dict (with or without the `text_model.` prefix; tensors or arrays) ->
+    {our parameter name: array} for kind "clip_torch" (q/k/v stacked into the reference's in_proj)."""
+    pre = "text_model." if any(k.startswith("text_model.") for k in state) else ""
+
+    def g(k):
+        v = state[pre + k]
+        return np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+
+    out = {"embedding.token.weight": g("embeddings.token_embedding.weight"),
+           "embedding.position": g("embeddings.position_embedding.weight").reshape(-1),
+           "layernorm.weight": g("final_layer_norm.weight"), "layernorm.bias": g("final_layer_norm.bias")}
+    for i in range(12):
+        h, n = f"encoder.layers.{i}.", f"player{i + 1}"
+        out[n + ".layer2.in_proj.weight"] = np.concatenate([g(h + f"self_attn.{x}_proj.weight") for x in "qkv"])
+        out[n + ".layer2.in_proj.bias"] = np.concatenate([g(h + f"self_attn.{x}_proj.bias") for x in "qkv"])
+        for ours, theirs in (("layer2.out_proj", "self_attn.out_proj"), ("layer4", "mlp.fc1"), ("layer5", "mlp.fc2"),
+                             ("layer1", "layer_norm1"), ("layer3", "layer_norm2")):
+            out[f"{n}.{ours}.weight"], out[f"{n}.{ours}.bias"] = g(h + theirs + ".weight"), g(h + theirs + ".bias")
+    return out
+
+
+def load_clip_text(path_or_state, ctx=None):
+    """tsd.CLIP(variant="clip_torch") from a CLIPTextModel safetensors file (e.g. `text_encoder/model.safetensors` of an
+    SD-1.x repository) or an in-memory state dict."""
+    from .clip import CLIP
+    state = read_safetensors(path_or_state) if isinstance(path_or_state, str) else path_or_state
+    return CLIP(ctx=ctx, params=hf_clip_text_to_params(state), variant="clip_torch")

@@ -16,8 +16,10 @@ class CLIP:
     forward(tokens): int ids, shape (T,) or (B, T) with T <= 77 (zero-padded to 77 like clip.mojo:91-93)
     -> (77, 768) or (B, 77, 768) float32: the `context` of Diffusion.forward / generate."""
 
-    def __init__(self, seed=0, ctx=None, params=None):
-        self.model = Model("clip", ctx=ctx, seed=None if params is not None else seed)
+    def __init__(self, seed=0, ctx=None, params=None, variant="clip"):
+        """variant "clip_torch" (extension): torch LayerNorms with weight / bias = Hugging Face's CLIPTextModel, for real
+        checkpoints (tsd.checkpoint.load_clip_text)."""
+        self.model = Model(variant, ctx=ctx, seed=None if params is not None else seed)
         if params is not None:
             self.model.load_params(params)
 

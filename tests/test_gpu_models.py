@@ -332,6 +332,41 @@ def test_torch_norm_unet_and_checkpoint_import(gpu_ctx, tsd_mod):
     d.model.close()
 
 
+def test_clip_torch_variant_matches_transformers(gpu_ctx, tsd_mod):
+    """The product itself against an independent implementation: Hugging Face's CLIPTextModel (full 49408-token vocabulary,
+    random weights including the LayerNorm affines) -> tsd.checkpoint key map -> libtsd `clip_torch`; same token ids in,
+    same (77, 768) context out, within the model tolerance.  Also checked against the oracle's torch-norm restatement."""
+    tr = pytest.importorskip("transformers")
+    import torch
+    from tsd import checkpoint as ck
+    torch.manual_seed(0)
+    cfg = tr.CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                            num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                            eos_token_id=49407, bos_token_id=49406, pad_token_id=0)
+    m = tr.CLIPTextModel(cfg).eval()
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if "layer_norm" in k:
+                v.copy_((1.0 if k.endswith("weight") else 0.0) + 0.2 * torch.randn_like(v))
+            elif "embedding" in k:
+                v.normal_(0, 1.0)
+            elif k.endswith("weight"):
+                v.normal_(0, 1.0 / np.sqrt(v.shape[1]))
+            else:
+                v.normal_(0, 0.1)
+    clip = ck.load_clip_text(m.state_dict())
+    tok = np.random.RandomState(3).randint(1, 49405, size=(2, 77))
+    tok[1, 40:] = 0  # a padded prompt
+    with torch.no_grad():
+        ref = m(input_ids=torch.from_numpy(tok)).last_hidden_state.numpy()
+    out = clip.forward(tok)
+    assert_close(out, ref, TOL_MODEL, None, "clip_torch vs transformers.CLIPTextModel")
+    P = ck.hf_clip_text_to_params(m.state_dict())
+    orc = np.stack([models.clip(P, tok[b], tn=True) for b in range(2)])
+    assert rel_l2(orc, ref) < 1e-4
+    clip.model.close()
+
+
 def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
     """The 16x16 level runs split-K with an in-launch hand-off (sc1 stores -> relaxed flag -> sc1 loads): after a
     headline-size forward no consumer may have timed out waiting for its partner, and the result is reproducible."""
