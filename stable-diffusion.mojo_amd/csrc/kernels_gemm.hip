@@ -841,8 +841,11 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
     ways = K >= min_k ? 2 : 1;
     if (cfg) *cfg = n160 ? 5 : 8;
   }
-  const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
-  if (ways == 1 || tiles > max_tiles || tiles % 8 || (ways - 1) * tiles > 4095) return 1;
+  // Eligibility looks at N only (8 | N-tiles keeps a tile's slices on one XCD for any M): a condition on the tile
+  // count would make the split - and with it the fp32 summation tree - depend on the batch.  The two M-dependent
+  // guards below cannot trigger inside the API's limits (B <= 16 with rps <= 256 gives at most 256 tiles).
+  const int tiles_n = ceil_div(N, BN), tiles = ceil_div(M, BM) * tiles_n;
+  if (ways == 1 || tiles_n % 8 || tiles > 2 * max_tiles || (ways - 1) * tiles > 4095) return 1;
   return ways;
 }
 static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
