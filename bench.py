@@ -132,7 +132,10 @@ def main():
     # device, gloo for the control collectives); the real run is one rank per GPU over RCCL.
     dev_index = int(os.environ.get("TSD_BENCH_DEVICE", local_rank))
     backend = os.environ.get("TSD_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # TSD_BENCH_FORCE_DIST=1 takes the torch.distributed path (RCCL init, blob broadcast, barrier, MAX-reduce) even with
+    # one rank, so the coexistence of torch's RCCL and libtsd in one process can be exercised on a one-GPU box.
+    use_dist = world > 1 or os.environ.get("TSD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
@@ -147,7 +150,7 @@ def main():
     unet = tsd.Diffusion(seed=SEED if rank == 0 else None, ctx=ctx)
     dec = None if args.no_decode else tsd.Decoder(seed=SEED if rank == 0 else None, ctx=ctx)
     bcast_s, bcast_bytes, bcast_how = 0.0, 0, "none (single GPU)"
-    if world > 1:
+    if use_dist:
         models = [unet.model] + ([dec.model] if dec is not None else [])
         try:
             if backend != "nccl":

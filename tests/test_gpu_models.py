@@ -366,6 +366,22 @@ def test_clip_torch_variant_matches_transformers(gpu_ctx, tsd_mod, tmp_path):
     clip.model.close()
 
 
+def test_bench_distributed_path_single_rank(gpu_ctx):
+    """bench.py's multi-GPU code path (torch.distributed over RCCL: init, packed-blob broadcast into libtsd's weights,
+    barrier, MAX-reduced time) exercised with one rank - torch's RCCL and libtsd in one process, as on an 8-GPU node."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSD_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-decode"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["output_finite"] and d["value"] > 10
+    assert d["weight_broadcast"].startswith("rccl broadcast") and d["weight_broadcast_bytes"] > 5e8
+
+
 def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
     """The 16x16 level runs split-K with an in-launch hand-off (sc1 stores -> relaxed flag -> sc1 loads): after a
     headline-size forward no consumer may have timed out waiting for its partner, and the result is reproducible."""
