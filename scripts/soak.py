@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.join(ROOT, "stable-diffusion.mojo_amd"))
 import tsd
 from tsd._lib import lib
 N = int(os.environ.get("STEPS", 3000))
-u = tsd.Diffusion(seed=1234)
-B, L, T, n = 8, 64, 77, 50
+u = tsd.Diffusion(seed=1234, variant=os.environ.get("VARIANT", "diffusion"))
+B, L, T, n = int(os.environ.get("B", 8)), 64, 77, 50
 lat = tsd.rng.normal(9, 1, B * 4 * L * L).reshape(B, 4, L, L)
 cx = tsd.rng.normal(9, 2, B * T * 768).reshape(B, T, 768)
 nz = tsd.rng.normal(9, 3, n * B * 4 * L * L).reshape(n, B, 4, L, L)
