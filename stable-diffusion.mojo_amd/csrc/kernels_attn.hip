@@ -43,6 +43,13 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// a*b + c as ONE unpacked v_fma_f32 (the SLP vectoriser would pair two of them into v_pk_fma_f32)
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 template <int D, int NST>
 // min 2 waves/SIMD: caps the budget at 256 unified registers so the MFMA results stay in VGPRs (no v_accvgpr moves
 // around the softmax / rescale VALU work).
@@ -253,7 +260,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
         }
     }
     const float nmc = -m_run * p.c;
-    const f2 c2 = {p.c, p.c}, m2 = {nmc, nmc};
     f2 psum2 = {0.f, 0.f};
     // P^T chunk kq (8 keys per lane) feeds the P.V MFMAs of chunk kq only, so the exponentials of chunk kq+1 are issued
     // between those MFMAs: the matrix pipe works through chunk kq while the VALU (exp2 is the slow part) produces the
@@ -263,9 +269,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
       const int kb = kq >> 1, r0 = (kq & 1) * 8;
 #pragma unroll
       for (int r = 0; r < 8; r += 2) {
-        f2 e = {s[kb][r0 + r], s[kb][r0 + r + 1]};
-        e = e * c2 + m2;  // v_pk_fma_f32
-        const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+        // two v_fma_f32, not one v_pk_fma_f32: next to MFMAs the packed form costs more than it saves
+        // (scripts/micro/mfma_valu_overlap.hip: 64 pk_fma add 645 ns to 8 MFMAs, 64 v_fma_f32 add 155 ns)
+        const float e0 = fma1(s[kb][r0 + r], p.c, nmc), e1 = fma1(s[kb][r0 + r + 1], p.c, nmc);
+        const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
         if (!ONES_ROW) psum2 += f2{p0, p1};
         pf[r] = (half_t)p0;
         pf[r + 1] = (half_t)p1;
@@ -291,9 +298,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
           sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][blk], qf[ks], sn[blk], 0, 0, 0);
         }
         const int r = i * 2;
-        f2 e = {s[0][r], s[0][r + 1]};
-        e = e * c2 + m2;
-        const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+        const float e0 = fma1(s[0][r], p.c, nmc), e1 = fma1(s[0][r + 1], p.c, nmc);
+        const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
         if (!ONES_ROW) psum2 += f2{p0, p1};
         pf_cur[r] = (half_t)p0;
         pf_cur[r + 1] = (half_t)p1;
