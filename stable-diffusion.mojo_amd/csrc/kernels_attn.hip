@@ -22,6 +22,8 @@
 //     so all ds_read_b128 are bank-conflict-free.
 #include <stdlib.h>
 
+#include <vector>
+#include <algorithm>
 #include "common.h"
 #include "lds_dma.h"
 
@@ -43,6 +45,9 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+#ifdef TSD_ATTN_TS
+__device__ unsigned long long g_attn_ts[4 * 65536];  // per block: memtime start/end, memrealtime start/end
+#endif
 // a*b + c as ONE unpacked v_fma_f32 (the SLP vectoriser would pair two of them into v_pk_fma_f32)
 __device__ __forceinline__ float fma1(float a, float b, float c) {
   float r;
@@ -75,6 +80,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3);  // accumulator holding row D (lanes hi=0)
   static_assert(!ONES_ROW || (((D % 32) >> 2) & 1) == 0, "row D must live in the hi=0 half");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef TSD_ATTN_TS
+  const int ts_blk = blockIdx.x + blockIdx.y * gridDim.x;
+  if (threadIdx.x == 0 && ts_blk < 65536) { g_attn_ts[ts_blk * 4] = __builtin_amdgcn_s_memtime(); g_attn_ts[ts_blk * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -331,6 +340,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     tile(t, sA, sB);
     if (t + 1 < ntiles) tile(t + 1, sB, sA);
   }
+#ifdef TSD_ATTN_TS
+  if (threadIdx.x == 0 && ts_blk < 65536) { g_attn_ts[ts_blk * 4 + 1] = __builtin_amdgcn_s_memtime(); g_attn_ts[ts_blk * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
   // ---- normalise and store O[b][q][h*D + d] -----------------------------------------------------
   float l_tot;
@@ -434,6 +446,22 @@ extern "C" int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, i
   float t = 0.f;
   HIP_TRY(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
   *ms = t / iters;
+#ifdef TSD_ATTN_TS
+  {
+    const int nblk = std::min(65536, ((Sq + 127) / 128) * B * H);
+    std::vector<unsigned long long> h((size_t)nblk * 4);
+    HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_attn_ts), h.size() * 8));
+    double clk = 0, dur = 0; int n = 0;
+    unsigned long long r0 = ~0ull, r1 = 0;
+    for (int b = 0; b < nblk; b++) {
+      const double dt = (double)(h[b * 4 + 1] - h[b * 4]), dr = (double)(h[b * 4 + 3] - h[b * 4 + 2]);
+      if (dr > 0) { clk += dt / (dr * 10.0); dur += dr * 10.0; n++; }  // realtime ticks are 10 ns
+      r0 = std::min(r0, h[b * 4 + 2]); r1 = std::max(r1, h[b * 4 + 3]);
+    }
+    fprintf(stderr, "[attn ts] blocks=%d mean block loop %.1f us, s_memtime ticks per ns %.3f, first-start..last-end %.1f us\n", n,
+            dur / n * 1e-3, clk / n, (r1 - r0) * 0.01);
+  }
+#endif
   ctx->arena.top = 0;
   return r;
 }
