@@ -209,6 +209,7 @@ def main():
         ctx.profile_begin()
         for i in range(P):
             sess.step((W + i) % n_sched)
+        recs = ctx.profile_records()  # per launch: (class, M, N, K, batch, ms) - read before profile_end() clears them
         prof = ctx.profile_end()
         per_step = {k: (ms / P, n // P) for k, (ms, n) in prof.items()}
         # A hipEvent pair brackets a launch PLUS its dispatch gaps; summed over the ~190 launches of a step the bracketed
@@ -239,6 +240,23 @@ def main():
                     "event_overhead_us_per_launch_removed": round(1e3 * ev_overhead_ms, 3),
                     "per_class_ms_per_step": {k: round(v[0], 4) for k, v in per_step.items()},
                     "per_class_launches_per_step": {k: v[1] for k, v in per_step.items()}}
+        # secondary kernels against their own rooflines (same pass, same per-launch correction): attention on the fp16
+        # MFMA peak (algorithmic 4*B*H*Sq*Sk*d per launch), the norms on HBM (algorithmic bytes = read once + write once)
+        sec = {}
+        for cls in ("flash_attention", "groupnorm", "layernorm"):
+            ms_c, n_c = per_step[cls]
+            if ms_c <= 0:
+                continue
+            rs = [r for r in recs if r[0] == cls]
+            if cls == "flash_attention":
+                tf = sum(4.0 * r[1] * r[2] * r[3] * r[4] for r in rs) / P / 1e12 / (ms_c / 1e3)
+                sec[cls] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / PEAK_FP16_TFLOPS, 4), "ms_per_step": round(ms_c, 4)}
+            else:
+                gbs = sum(2.0 * r[1] * r[2] * 2 for r in rs) / P / 1e9 / (ms_c / 1e3)
+                sec[cls] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(gbs / 8000.0, 4), "ms_per_step": round(ms_c, 4)}
+        roofline["secondary_kernels"] = sec
         # ---- VAE decode time (images/s end-to-end = B / (50 * step + decode)) ----
         dec_ms = None
         if dec is not None:
