@@ -319,7 +319,7 @@ def main():
             enc.model.close()
         images_per_s = (world * B) / ((n_sched * ms_per_step + (dec_ms or 0.0)) / 1e3)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 figure
             t_sample = cpu_baseline(L, T)
             cpu = {"value": round(1.0 / (B * t_sample), 6), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"one sample-step (1/{B} of a batch-{B} step: Diffusion.forward + DDPM update, L={L}, T={T}) "
