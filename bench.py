@@ -321,7 +321,13 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 figure
             t_sample = cpu_baseline(L, T)
-            cpu = {"value": round(1.0 / (B * t_sample), 6), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+            try:  # threads the numpy oracle's BLAS actually runs on (its pool may be smaller than the host's core count)
+                from threadpoolctl import threadpool_info
+                blas_threads = max([p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"] or [os.cpu_count()])
+            except Exception:
+                blas_threads = os.cpu_count()
+            cpu = {"value": round(1.0 / (B * t_sample), 6), "unit": "steps/s", "cores": blas_threads, "kind": "port",
+                   "host_cores": os.cpu_count(),
                    "sample": f"one sample-step (1/{B} of a batch-{B} step: Diffusion.forward + DDPM update, L={L}, T={T}) "
                              f"of the numpy oracle took {t_sample:.1f} s; value = 1/({B} x that)"}
         whole_frac = steps_per_s / world * B * total_gf / 1e3 / PEAK_FP16_TFLOPS
