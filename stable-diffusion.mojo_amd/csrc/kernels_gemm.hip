@@ -838,7 +838,8 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
     static const int deep = getenv("TSD_GEMM_SPLITK_RING4") ? atoi(getenv("TSD_GEMM_SPLITK_RING4")) : 0;
     if (cfg) *cfg = deep ? (n160 ? 6 : 9) : (n160 ? 7 : 10);
   } else {
-    ways = K >= min_k ? 2 : 1;
+    static const int big_ways = getenv("TSD_GEMM_SPLITK_BIG") ? atoi(getenv("TSD_GEMM_SPLITK_BIG")) : 2;
+    ways = K >= 8192 ? big_ways : (K >= min_k ? 2 : 1);
     if (cfg) *cfg = n160 ? 5 : 8;
   }
   // Eligibility looks at N only (8 | N-tiles keeps a tile's slices on one XCD for any M): a condition on the tile
