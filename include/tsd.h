@@ -181,8 +181,12 @@ int tsd_vae_attention_block_f32(tsd_ctx* ctx, const float* x, int C, int H, int 
  * struct), eps sits inside the root, and the output layer's GroupNorm has 32 groups.
  * TSD_MODEL_CLIP_TORCH: the CLIP text encoder (clip.mojo:74-109) with torch LayerNorms - weight and bias of the two
  * LayerNorms of every layer (`playerN.layer1`, `playerN.layer3`) and of the final one (`layernorm`) appended to the
- * kind-4 parameter list; this is exactly Hugging Face's CLIPTextModel (the ViT-L/14 text tower SD-1.x conditions on). */
-typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5, TSD_MODEL_DIFFUSION_SD15_TORCH = 6, TSD_MODEL_CLIP_TORCH = 7 } tsd_model_kind;
+ * kind-4 parameter list; this is exactly Hugging Face's CLIPTextModel (the ViT-L/14 text tower SD-1.x conditions on).
+ * TSD_MODEL_DECODER_TORCH / TSD_MODEL_ENCODER_TORCH: the VAE graphs (vae.mojo:94-112,194-219) with the trained VAE's
+ * norms - 32 groups in the residual blocks (the reference declares 16, vae.mojo:42-43), per-channel weight / bias of
+ * every GroupNorm appended to the kind-2 / kind-3 list (`lN.group_norm1`, `lN.group_norm2`, `lN.group_norm`, and
+ * `lN` for the stand-alone norm), eps inside the root: the layout of diffusers' AutoencoderKL decoder / encoder. */
+typedef enum tsd_model_kind { TSD_MODEL_DIFFUSION = 1, TSD_MODEL_DECODER = 2, TSD_MODEL_ENCODER = 3, TSD_MODEL_CLIP = 4, TSD_MODEL_DIFFUSION_SD15 = 5, TSD_MODEL_DIFFUSION_SD15_TORCH = 6, TSD_MODEL_CLIP_TORCH = 7, TSD_MODEL_DECODER_TORCH = 8, TSD_MODEL_ENCODER_TORCH = 9 } tsd_model_kind;
 
 /* Parameter inventory in struct-field DFS order: `Diffusion`
  * diffusion.mojo:299-302, `Decoder` vae.mojo:194-219, `Encoder` vae.mojo:94-112.  No GPU needed. */

@@ -193,29 +193,30 @@ def diffusion(P, x, context, t320, sem=DEFAULT, trace=None):
 # vae.mojo
 
 
-def vae_attention_block(P, prefix, x, sem=DEFAULT):
+def vae_attention_block(P, prefix, x, sem=DEFAULT, tn=False):
     """`Attention_Block.forward` vae.mojo:17-27: GN32 -> tokens -> Self_Attention(1 head, biases on) -> + x."""
     C, H, W = x.shape
-    h = ops.group_norm(x, 32, C)
+    h = _gn(P, prefix + ".group_norm", x, 32, C, 1e-5, tn)
     tok = ops.chw_to_tokens(h)
     tok = ops.self_attention(tok, 1, P[prefix + ".attention.in_proj.weight"], P[prefix + ".attention.in_proj.bias"],
                              P[prefix + ".attention.out_proj.weight"], P[prefix + ".attention.out_proj.bias"], sem=sem)
     return ops.tokens_to_chw(tok, H, W) + x
 
 
-def vae_res_block(P, prefix, x, cin, cout):
+def vae_res_block(P, prefix, x, cin, cout, tn=False):
     """`Res_Block.forward` vae.mojo:57-67: GN16 -> SiLU -> Conv3x3 -> GN16 -> SiLU -> Conv3x3 ; + x or + Conv1x1(x)."""
-    h = ops.group_norm(x, 16, cin)
+    g = 32 if tn else 16  # the trained VAE has 32 groups (extension); the reference declares 16 (vae.mojo:42-43)
+    h = _gn(P, prefix + ".group_norm1", x, g, cin, 1e-5, tn)
     h = ops.silu(h)
     h = _conv(P, prefix + ".conv1", h, (1, 1))
-    h = ops.group_norm(h, 16, cout)
+    h = _gn(P, prefix + ".group_norm2", h, g, cout, 1e-5, tn)
     h = ops.silu(h)
     h = _conv(P, prefix + ".conv2", h, (1, 1))
     res = x if cin == cout else _conv(P, prefix + ".res_conv_layer", x, (0, 0))
     return h + res
 
 
-def _vae_run(P, layers, x, sem, trace=None):
+def _vae_run(P, layers, x, sem, trace=None, tn=False):
     h = x
     for i, (kind, a) in enumerate(layers, start=1):
         name = f"l{i}"
@@ -225,13 +226,13 @@ def _vae_run(P, layers, x, sem, trace=None):
         elif kind == "conv_s2":      # vae.mojo:138-139: pad (0,1),(0,1) then stride-2 conv without padding
             h = _conv(P, name, h, (0, 0), stride=(2, 2), pad_hw=((0, 1), (0, 1)))
         elif kind == "res":
-            h = vae_res_block(P, name, h, *a)
+            h = vae_res_block(P, name, h, *a, tn=tn)
         elif kind == "attn":
-            h = vae_attention_block(P, name, h, sem)
+            h = vae_attention_block(P, name, h, sem, tn=tn)
         elif kind == "up":
             h = ops.upsample_nearest2x(h)
         elif kind == "gn":
-            h = ops.group_norm(h, a[0], a[1])
+            h = _gn(P, name, h, a[0], a[1], 1e-5, tn)
         elif kind == "silu":
             h = ops.silu(h)
         if trace is not None:
@@ -239,17 +240,17 @@ def _vae_run(P, layers, x, sem, trace=None):
     return h
 
 
-def decoder(P, x, sem=DEFAULT, trace=None):
+def decoder(P, x, sem=DEFAULT, trace=None, tn=False):
     """`Decoder.forward` vae.mojo:221-250: x/0.18215 then 26 layers; (4,L,L) -> (3,8L,8L).  Pure (App.A D14)."""
-    return _vae_run(P, DECODER_LAYERS, x / x.dtype.type(0.18215), sem, trace)
+    return _vae_run(P, DECODER_LAYERS, x / x.dtype.type(0.18215), sem, trace, tn=tn)
 
 
-def encoder(P, x, noise, sem=DEFAULT, trace=None):
+def encoder(P, x, noise, sem=DEFAULT, trace=None, tn=False):
     """`Encoder.forward` vae.mojo:131-159 + `metrics_evals` :118-129.
 
     (3,S,S) -> (8,S/8,S/8) -> mean, logvar = chunk(0,2); logvar clamp(-30,20);
     out = (mean + noise*exp(0.5*logvar)) * 0.18215."""
-    h = _vae_run(P, ENCODER_LAYERS, x, sem, trace)
+    h = _vae_run(P, ENCODER_LAYERS, x, sem, trace, tn=tn)
     mean, logvar = np.split(h, 2, axis=0)
     logvar = np.clip(logvar, -30.0, 20.0)
     std = np.sqrt(np.exp(logvar))

@@ -245,6 +245,29 @@ def clip_params() -> List[Param]:
     return out
 
 
+def _vae_torch_params(layers) -> List[Param]:
+    """VAE graph with the trained VAE's norms (extension): the reference list + weight/bias of every GroupNorm."""
+    out = _vae_params(layers)
+    for i, (kind, a) in enumerate(layers, start=1):
+        name = f"l{i}"
+        if kind == "res":
+            _norm(out, name + ".group_norm1", a[0])
+            _norm(out, name + ".group_norm2", a[1])
+        elif kind == "attn":
+            _norm(out, name + ".group_norm", a[0])
+        elif kind == "gn":
+            _norm(out, name, a[1])
+    return out
+
+
+def decoder_torch_params() -> List[Param]:
+    return _vae_torch_params(DECODER_LAYERS)
+
+
+def encoder_torch_params() -> List[Param]:
+    return _vae_torch_params(ENCODER_LAYERS)
+
+
 def clip_torch_params() -> List[Param]:
     """CLIP text encoder with torch LayerNorms (extension): the kind-4 list + weight/bias of every LayerNorm."""
     out = clip_params()
@@ -255,7 +278,8 @@ def clip_torch_params() -> List[Param]:
     return out
 
 
-MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5, "diffusion_sd15_torch": 6, "clip_torch": 7}
+MODEL_IDS = {"diffusion": 1, "decoder": 2, "encoder": 3, "clip": 4, "diffusion_sd15": 5, "diffusion_sd15_torch": 6, "clip_torch": 7,
+             "decoder_torch": 8, "encoder_torch": 9}
 
 
 def tensor_id(model: str, index: int) -> int:
@@ -266,7 +290,8 @@ def tensor_id(model: str, index: int) -> int:
 def init_params(model: str, seed: int, only_used=False):
     """Generate the synthetic weights of `model` ('diffusion'|'decoder'|'encoder'|'clip'|'diffusion_sd15') -> {name: array}."""
     plist = {"diffusion": diffusion_params, "decoder": decoder_params, "encoder": encoder_params, "clip": clip_params,
-             "diffusion_sd15": diffusion_sd15_params, "diffusion_sd15_torch": diffusion_sd15_torch_params, "clip_torch": clip_torch_params}[model]()
+             "diffusion_sd15": diffusion_sd15_params, "diffusion_sd15_torch": diffusion_sd15_torch_params, "clip_torch": clip_torch_params,
+             "decoder_torch": decoder_torch_params, "encoder_torch": encoder_torch_params}[model]()
     out = {}
     for i, p in enumerate(plist):
         if only_used and not p.used:

@@ -60,7 +60,7 @@ extern "C" int tsd_diffusion_forward(tsd_model* m, const float* latents, const f
 
 extern "C" int tsd_decoder_forward(tsd_model* m, const float* latents, int B, int L, float* images) {
   NOTNULL(m); NOTNULL(latents); NOTNULL(images);
-  if (m->kind != TSD_MODEL_DECODER) TSD_FAIL(TSD_E_ARG, "tsd_decoder_forward: model is not a Decoder");
+  if (!is_decoder_kind(m->kind)) TSD_FAIL(TSD_E_ARG, "tsd_decoder_forward: model is not a Decoder");
   if (B <= 0 || L <= 0) TSD_FAIL(TSD_E_SHAPE, "decoder: B=%d L=%d", B, L);
   tsd_ctx* ctx = m->ctx;
   return run_model(m, [&]() -> int {
@@ -77,7 +77,7 @@ extern "C" int tsd_decoder_forward(tsd_model* m, const float* latents, int B, in
 extern "C" int tsd_encoder_forward(tsd_model* m, const float* images, const float* noise, int B, int S,
                                    float* latents) {
   NOTNULL(m); NOTNULL(images); NOTNULL(noise); NOTNULL(latents);
-  if (m->kind != TSD_MODEL_ENCODER) TSD_FAIL(TSD_E_ARG, "tsd_encoder_forward: model is not an Encoder");
+  if (!is_encoder_kind(m->kind)) TSD_FAIL(TSD_E_ARG, "tsd_encoder_forward: model is not an Encoder");
   if (B <= 0 || S <= 0 || S % 8) TSD_FAIL(TSD_E_SHAPE, "encoder: B=%d S=%d", B, S);
   tsd_ctx* ctx = m->ctx;
   return run_model(m, [&]() -> int {
@@ -163,7 +163,7 @@ extern "C" int tsd_session_create(tsd_model* diffusion, tsd_model* decoder, int 
                                   tsd_session** out) {
   NOTNULL(diffusion); NOTNULL(out);
   if (!is_diffusion_kind(diffusion->kind)) TSD_FAIL(TSD_E_ARG, "session: first model must be a Diffusion");
-  if (decoder && (decoder->kind != TSD_MODEL_DECODER || decoder->ctx != diffusion->ctx))
+  if (decoder && (!is_decoder_kind(decoder->kind) || decoder->ctx != diffusion->ctx))
     TSD_FAIL(TSD_E_ARG, "session: decoder must be a Decoder on the same context");
   const int Bu = cfg ? 2 * B : B;
   if (B <= 0 || Bu > 16 || L <= 0 || L % 8 || T <= 0) TSD_FAIL(TSD_E_SHAPE, "session: B=%d (UNet batch %d <= 16) L=%d T=%d", B, Bu, L, T);

@@ -260,7 +260,8 @@ int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act& out) {
   const size_t mark = ctx->arena.mark();
   half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
   const bool x_stats = x.gn_part && x.gn_groups == 32;
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-5f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr, x.gn_nslab));
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-5f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr, x.gn_nslab,
+                           w.gn.w ? &w.gn : nullptr));
   half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
   half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * S); CHECK_ALLOC(vt);
   half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
@@ -487,7 +488,7 @@ static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, 
       const int silu = (i + 1 < n_layers && layers[i + 1].kind == L_SILU) ? 1 : 0;
       const bool st = cur.gn_part && cur.gn_groups == l.a && cur.C == l.b;
       TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), l.b), B, cur.H * cur.W, l.b, l.a, 1e-5f, 1.f, silu, y.p, y.ld,
-                               st ? cur.gn_part : nullptr, cur.gn_nslab));
+                               st ? cur.gn_part : nullptr, cur.gn_nslab, v.gn[i].w ? &v.gn[i] : nullptr));
       cur = y;
       continue;
     }

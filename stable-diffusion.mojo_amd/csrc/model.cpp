@@ -259,9 +259,20 @@ int model_resolve(tsd_model* m) {
       c.layer[i].ln2 = aff(n + ".layer3");
     }
   } else {
-    const LayerDef* L = m->kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
-    const int n_layers = m->kind == TSD_MODEL_DECODER ? 26 : 19;
+    const LayerDef* L = is_decoder_kind(m->kind) ? DECODER_LAYERS : ENCODER_LAYERS;
+    const int n_layers = is_decoder_kind(m->kind) ? 26 : 19;
+    const bool torch_norms = is_vae_torch_kind(m->kind);
+    auto aff = [&](const std::string& name) {
+      NormAffine a;
+      if (torch_norms) {
+        a.w = (const float*)(m->blob + m->params[m->index.at(name + ".weight")].off);
+        a.b = (const float*)(m->blob + m->params[m->index.at(name + ".bias")].off);
+        a.torch_rstd = 1;
+      }
+      return a;
+    };
     VaeW& v = m->vae;
+    v.gn.assign(n_layers, NormAffine());
     v.conv.assign(n_layers, ConvW());
     v.res.assign(n_layers, ResW());
     v.attn.assign(n_layers, VaeAttnW());
@@ -271,7 +282,9 @@ int model_resolve(tsd_model* m) {
       if (l.kind == L_CONV || l.kind == L_CONV_S2) v.conv[i] = model_conv(m, n);
       else if (l.kind == L_RES) {
         ResW& r = v.res[i];
-        r.cin = l.a; r.cout = l.b; r.groups = 16; r.has_skip = l.a != l.b;  // GroupNorm(16), vae.mojo:42-43
+        r.cin = l.a; r.cout = l.b; r.has_skip = l.a != l.b;
+        r.groups = torch_norms ? 32 : 16;  // GroupNorm(16), vae.mojo:42-43 ; the trained VAE has 32
+        r.gn1 = aff(n + ".group_norm1"); r.gn2 = aff(n + ".group_norm2");
         r.conv1 = model_conv(m, n + ".conv1");
         r.conv2 = model_conv(m, n + ".conv2");
         if (r.has_skip) r.skip = model_conv(m, n + ".res_conv_layer");
@@ -279,6 +292,9 @@ int model_resolve(tsd_model* m) {
         v.attn[i].C = l.a;
         v.attn[i].in_proj = model_lin(m, n + ".attention.in_proj", true);
         v.attn[i].out_proj = model_lin(m, n + ".attention.out_proj", true);
+        v.attn[i].gn = aff(n + ".group_norm");
+      } else if (l.kind == L_GN) {
+        v.gn[i] = aff(n);
       }
     }
   }

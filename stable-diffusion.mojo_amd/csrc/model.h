@@ -42,7 +42,10 @@ extern const UNetStep SD15_STEPS[SD15_N];
 static inline bool is_full_unet_kind(int kind) { return kind == TSD_MODEL_DIFFUSION_SD15 || kind == TSD_MODEL_DIFFUSION_SD15_TORCH; }
 static inline bool is_diffusion_kind(int kind) { return kind == TSD_MODEL_DIFFUSION || is_full_unet_kind(kind); }
 static inline bool is_clip_kind(int kind) { return kind == TSD_MODEL_CLIP || kind == TSD_MODEL_CLIP_TORCH; }
-constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_CLIP_TORCH;
+static inline bool is_decoder_kind(int kind) { return kind == TSD_MODEL_DECODER || kind == TSD_MODEL_DECODER_TORCH; }
+static inline bool is_encoder_kind(int kind) { return kind == TSD_MODEL_ENCODER || kind == TSD_MODEL_ENCODER_TORCH; }
+static inline bool is_vae_torch_kind(int kind) { return kind == TSD_MODEL_DECODER_TORCH || kind == TSD_MODEL_ENCODER_TORCH; }
+constexpr int TSD_MODEL_KIND_MAX = TSD_MODEL_ENCODER_TORCH;
 
 std::vector<ParamSpec> build_param_specs(int model_kind);
 
@@ -64,6 +67,7 @@ struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
 struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;
   LinW in_proj, out_proj;
+  NormAffine gn;  // torch-norm extension (kinds 8, 9)
 };
 
 struct UNetW {
@@ -81,6 +85,7 @@ struct VaeW {
   std::vector<ConvW> conv;      // indexed by layer (1-based position - 1)
   std::vector<ResW> res;
   std::vector<VaeAttnW> attn;
+  std::vector<NormAffine> gn;   // stand-alone GroupNorm layers (torch-norm extension)
 };
 
 struct ClipLayerW { LinW in_proj, out_proj, l4, l5; NormAffine ln1, ln2; };  // ClipPlayer clip.mojo:23-34 (its LayerNorms have no parameters)

@@ -175,15 +175,24 @@ std::vector<ParamSpec> build_param_specs(int kind) {
       }
       b.norm("layernorm", 768);
     }
-  } else if (kind == TSD_MODEL_DECODER || kind == TSD_MODEL_ENCODER) {
-    const LayerDef* L = kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
-    const int n_layers = kind == TSD_MODEL_DECODER ? 26 : 19;
+  } else if (is_decoder_kind(kind) || is_encoder_kind(kind)) {
+    const LayerDef* L = is_decoder_kind(kind) ? DECODER_LAYERS : ENCODER_LAYERS;
+    const int n_layers = is_decoder_kind(kind) ? 26 : 19;
     for (int i = 0; i < n_layers; i++) {
       const LayerDef& l = L[i];
       const std::string n = "l" + std::to_string(i + 1);
       if (l.kind == L_CONV || l.kind == L_CONV_S2) b.conv(n, l.a, l.b, l.c, true, i == n_layers - 1);
       else if (l.kind == L_RES) b.vae_res(n, l.a, l.b);
       else if (l.kind == L_ATTN) b.vae_attn(n, l.a);
+    }
+    if (is_vae_torch_kind(kind)) {  // norm parameters appended, so the shared indices equal the reference kind's
+      for (int i = 0; i < n_layers; i++) {
+        const LayerDef& l = L[i];
+        const std::string n = "l" + std::to_string(i + 1);
+        if (l.kind == L_RES) { b.norm(n + ".group_norm1", l.a); b.norm(n + ".group_norm2", l.b); }
+        else if (l.kind == L_ATTN) b.norm(n + ".group_norm", l.a);
+        else if (l.kind == L_GN) b.norm(n, l.b);
+      }
     }
   }
   return b.out;
@@ -267,9 +276,9 @@ extern "C" double tsd_flop_count(int kind, int L, int T) {
       else if (l.kind == L_ATTN) f += unet_attn_f((double)l.a * l.b, l.b, side * side, T);
     }
     f += conv_f(320, 4, 3, (double)L * L);
-  } else if (kind == TSD_MODEL_DECODER || kind == TSD_MODEL_ENCODER) {
-    const LayerDef* Ls = kind == TSD_MODEL_DECODER ? DECODER_LAYERS : ENCODER_LAYERS;
-    const int n = kind == TSD_MODEL_DECODER ? 26 : 19;
+  } else if (is_decoder_kind(kind) || is_encoder_kind(kind)) {
+    const LayerDef* Ls = is_decoder_kind(kind) ? DECODER_LAYERS : ENCODER_LAYERS;
+    const int n = is_decoder_kind(kind) ? 26 : 19;
     double side = L;  // decoder: latent side ; encoder: image side
     for (int i = 0; i < n; i++) {
       const LayerDef& l = Ls[i];

@@ -20,7 +20,7 @@ TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 MODEL_DIFFUSION, MODEL_DECODER, MODEL_ENCODER, MODEL_CLIP, MODEL_DIFFUSION_SD15, MODEL_DIFFUSION_SD15_TORCH = 1, 2, 3, 4, 5, 6
-MODEL_CLIP_TORCH = 7
+MODEL_CLIP_TORCH, MODEL_DECODER_TORCH, MODEL_ENCODER_TORCH = 7, 8, 9
 
 
 class TsdError(RuntimeError):

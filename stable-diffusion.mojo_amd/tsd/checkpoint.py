@@ -213,3 +213,111 @@ def load_clip_text(path_or_state, ctx=None):
     from .clip import CLIP
     state = read_safetensors(path_or_state) if isinstance(path_or_state, str) else path_or_state
     return CLIP(ctx=ctx, params=hf_clip_text_to_params(state), variant="clip_torch")
+
+
+# ---- VAE (diffusers AutoencoderKL) ---------------------------------------------------------------------------------
+# layer position in DECODER_LAYERS / ENCODER_LAYERS (1-based) -> diffusers module; None = no parameters
+VAE_DECODER_MODULES = {1: "post_quant_conv", 2: "decoder.conv_in", 3: "decoder.mid_block.resnets.0",
+                       4: "decoder.mid_block.attentions.0", 5: "decoder.mid_block.resnets.1",
+                       6: "decoder.up_blocks.0.resnets.0", 7: "decoder.up_blocks.0.resnets.1", 8: "decoder.up_blocks.0.resnets.2",
+                       10: "decoder.up_blocks.0.upsamplers.0.conv",
+                       11: "decoder.up_blocks.1.resnets.0", 12: "decoder.up_blocks.1.resnets.1", 13: "decoder.up_blocks.1.resnets.2",
+                       15: "decoder.up_blocks.1.upsamplers.0.conv",
+                       16: "decoder.up_blocks.2.resnets.0", 17: "decoder.up_blocks.2.resnets.1", 18: "decoder.up_blocks.2.resnets.2",
+                       20: "decoder.up_blocks.2.upsamplers.0.conv",
+                       21: "decoder.up_blocks.3.resnets.0", 22: "decoder.up_blocks.3.resnets.1", 23: "decoder.up_blocks.3.resnets.2",
+                       24: "decoder.conv_norm_out", 26: "decoder.conv_out"}
+VAE_ENCODER_MODULES = {1: "encoder.conv_in", 2: "encoder.down_blocks.0.resnets.0", 3: "encoder.down_blocks.0.resnets.1",
+                       4: "encoder.down_blocks.0.downsamplers.0.conv",
+                       5: "encoder.down_blocks.1.resnets.0", 6: "encoder.down_blocks.1.resnets.1",
+                       7: "encoder.down_blocks.1.downsamplers.0.conv",
+                       8: "encoder.down_blocks.2.resnets.0", 9: "encoder.down_blocks.2.resnets.1",
+                       10: "encoder.down_blocks.2.downsamplers.0.conv",
+                       11: "encoder.down_blocks.3.resnets.0", 12: "encoder.down_blocks.3.resnets.1",
+                       13: "encoder.mid_block.resnets.0", 14: "encoder.mid_block.attentions.0", 15: "encoder.mid_block.resnets.1",
+                       16: "encoder.conv_norm_out", 18: "encoder.conv_out", 19: "quant_conv"}
+_VRES = [("group_norm1.weight", "norm1.weight"), ("group_norm1.bias", "norm1.bias"), ("conv1.kernel", "conv1.weight"),
+         ("conv1.bias", "conv1.bias"), ("group_norm2.weight", "norm2.weight"), ("group_norm2.bias", "norm2.bias"),
+         ("conv2.kernel", "conv2.weight"), ("conv2.bias", "conv2.bias")]
+_VRES_SKIP = [("res_conv_layer.kernel", "conv_shortcut.weight"), ("res_conv_layer.bias", "conv_shortcut.bias")]
+
+
+def _vae_kinds(which):
+    from .model import param_specs
+    fields = {}
+    for name, _, _, _ in param_specs(which + "_torch"):
+        i, f = name.split(".", 1)
+        fields.setdefault(int(i[1:]), set()).add(f)
+    return {i: ("attn" if "attention.in_proj.weight" in f else "res" if "conv1.kernel" in f else
+                "conv" if "kernel" in f else "gn") for i, f in fields.items()}
+
+
+def diffusers_vae_to_params(state, which):
+    """diffusers AutoencoderKL state dict -> {our parameter name: array} for kind "decoder_torch" / "encoder_torch".
+    Attention projections may be named to_q/to_k/to_v/to_out.0 (current) or query/key/value/proj_attn (older files);
+    1x1-conv shaped attention weights (C, C, 1, 1) are flattened."""
+    mods = VAE_DECODER_MODULES if which == "decoder" else VAE_ENCODER_MODULES
+    g = lambda k: np.asarray(state[k], dtype=np.float32)  # noqa: E731
+    out = {}
+    for i, kind in _vae_kinds(which).items():
+        n, mod = f"l{i}", mods[i]
+        if kind == "conv":
+            out[n + ".kernel"], out[n + ".bias"] = g(mod + ".weight"), g(mod + ".bias")
+        elif kind == "gn":
+            out[n + ".weight"], out[n + ".bias"] = g(mod + ".weight"), g(mod + ".bias")
+        elif kind == "res":
+            for ours, theirs in _VRES:
+                out[f"{n}.{ours}"] = g(f"{mod}.{theirs}")
+            if f"{mod}.conv_shortcut.weight" in state:
+                for ours, theirs in _VRES_SKIP:
+                    out[f"{n}.{ours}"] = g(f"{mod}.{theirs}")
+        else:
+            names = ("to_q", "to_k", "to_v", "to_out.0") if f"{mod}.to_q.weight" in state else ("query", "key", "value", "proj_attn")
+            flat = lambda k: g(k).reshape(g(k).shape[0], -1)  # noqa: E731
+            out[n + ".attention.in_proj.weight"] = np.concatenate([flat(f"{mod}.{x}.weight") for x in names[:3]])
+            out[n + ".attention.in_proj.bias"] = np.concatenate([g(f"{mod}.{x}.bias") for x in names[:3]])
+            out[n + ".attention.out_proj.weight"], out[n + ".attention.out_proj.bias"] = flat(f"{mod}.{names[3]}.weight"), g(f"{mod}.{names[3]}.bias")
+            out[n + ".group_norm.weight"], out[n + ".group_norm.bias"] = g(mod + ".group_norm.weight"), g(mod + ".group_norm.bias")
+    return out
+
+
+def params_to_diffusers_vae(params, which):
+    """Inverse of `diffusers_vae_to_params` (current diffusers attention names)."""
+    mods = VAE_DECODER_MODULES if which == "decoder" else VAE_ENCODER_MODULES
+    out = {}
+    for i, kind in _vae_kinds(which).items():
+        n, mod = f"l{i}", mods[i]
+        if kind == "conv":
+            out[mod + ".weight"], out[mod + ".bias"] = params[n + ".kernel"], params[n + ".bias"]
+        elif kind == "gn":
+            out[mod + ".weight"], out[mod + ".bias"] = params[n + ".weight"], params[n + ".bias"]
+        elif kind == "res":
+            for ours, theirs in _VRES:
+                out[f"{mod}.{theirs}"] = params[f"{n}.{ours}"]
+            w = params.get(n + ".res_conv_layer.kernel")
+            if w is not None and w.shape[0] != w.shape[1]:
+                for ours, theirs in _VRES_SKIP:
+                    out[f"{mod}.{theirs}"] = params[f"{n}.{ours}"]
+        else:
+            q, k, v = np.split(np.asarray(params[n + ".attention.in_proj.weight"]), 3)
+            bq, bk, bv = np.split(np.asarray(params[n + ".attention.in_proj.bias"]), 3)
+            for x, w, b in (("to_q", q, bq), ("to_k", k, bk), ("to_v", v, bv)):
+                out[f"{mod}.{x}.weight"], out[f"{mod}.{x}.bias"] = w, b
+            out[mod + ".to_out.0.weight"], out[mod + ".to_out.0.bias"] = params[n + ".attention.out_proj.weight"], params[n + ".attention.out_proj.bias"]
+            out[mod + ".group_norm.weight"], out[mod + ".group_norm.bias"] = params[n + ".group_norm.weight"], params[n + ".group_norm.bias"]
+    return out
+
+
+def load_vae(path_or_state, which="decoder", ctx=None):
+    """tsd.Decoder / tsd.Encoder (variant "*_torch") from a diffusers AutoencoderKL safetensors file
+    (`vae/diffusion_pytorch_model.safetensors`) or an in-memory state dict."""
+    from .model import param_specs
+    from .vae import Decoder, Encoder
+    state = read_safetensors(path_or_state) if isinstance(path_or_state, str) else path_or_state
+    params = diffusers_vae_to_params(state, which)
+    for name, shape, used, _ in param_specs(which + "_torch"):
+        if name not in params:
+            if used:
+                raise KeyError(f"checkpoint has no tensor for {name}")
+            params[name] = np.zeros(shape, np.float32)
+    return (Decoder if which == "decoder" else Encoder)(ctx=ctx, params=params, variant=which + "_torch")

@@ -8,7 +8,8 @@ from ._lib import check, f32, lib, ptr, vp
 
 KINDS = {"diffusion": _lib.MODEL_DIFFUSION, "decoder": _lib.MODEL_DECODER, "encoder": _lib.MODEL_ENCODER,
          "clip": _lib.MODEL_CLIP, "diffusion_sd15": _lib.MODEL_DIFFUSION_SD15,
-         "diffusion_sd15_torch": _lib.MODEL_DIFFUSION_SD15_TORCH, "clip_torch": _lib.MODEL_CLIP_TORCH}
+         "diffusion_sd15_torch": _lib.MODEL_DIFFUSION_SD15_TORCH, "clip_torch": _lib.MODEL_CLIP_TORCH,
+         "decoder_torch": _lib.MODEL_DECODER_TORCH, "encoder_torch": _lib.MODEL_ENCODER_TORCH}
 
 
 def param_specs(kind):

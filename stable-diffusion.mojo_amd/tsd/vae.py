@@ -54,8 +54,10 @@ class Res_Block:
 class Decoder:
     """`Decoder` vae.mojo:162-250.  forward(x): (4,L,L) or (B,4,L,L) -> (3,8L,8L) / (B,3,8L,8L)."""
 
-    def __init__(self, seed=0, ctx=None, params=None):
-        self.model = Model("decoder", ctx=ctx, seed=None if params is not None else seed)
+    def __init__(self, seed=0, ctx=None, params=None, variant="decoder"):
+        """variant "decoder_torch" (extension): the trained VAE's norms (32 groups, per-channel affine) for real
+        checkpoints (tsd.checkpoint.load_vae)."""
+        self.model = Model(variant, ctx=ctx, seed=None if params is not None else seed)
         if params is not None:
             self.model.load_params(params)
 
@@ -74,8 +76,8 @@ class Decoder:
 class Encoder:
     """`Encoder` vae.mojo:70-159.  forward(x, noise): (3,S,S),(4,S/8,S/8) -> (4,S/8,S/8) (batched variants too)."""
 
-    def __init__(self, seed=0, ctx=None, params=None):
-        self.model = Model("encoder", ctx=ctx, seed=None if params is not None else seed)
+    def __init__(self, seed=0, ctx=None, params=None, variant="encoder"):
+        self.model = Model(variant, ctx=ctx, seed=None if params is not None else seed)
         if params is not None:
             self.model.load_params(params)
 

@@ -24,7 +24,8 @@ def test_param_inventory_matches_oracle_spec(tsd_mod):
                         ("encoder", spec.encoder_params()), ("clip", spec.clip_params()),
                         ("diffusion_sd15", spec.diffusion_sd15_params()),
                         ("diffusion_sd15_torch", spec.diffusion_sd15_torch_params()),
-                        ("clip_torch", spec.clip_torch_params())):
+                        ("clip_torch", spec.clip_torch_params()), ("decoder_torch", spec.decoder_torch_params()),
+                        ("encoder_torch", spec.encoder_torch_params())):
         got = tsd_mod.param_specs(kind)
         assert len(got) == len(plist)
         for (name, shape, used, bound), p in zip(got, plist):

@@ -67,3 +67,32 @@ def test_key_map_matches_the_published_sd15_unet(tsd_mod):
             assert np.array_equal(a, P[name]), name
     with pytest.raises(KeyError):
         ck.diffusers_sd15_unet_to_params({k: v for k, v in sd.items() if k != "conv_in.weight"})
+
+
+def test_vae_key_map_matches_the_published_autoencoder(tsd_mod):
+    """The SD-1.x VAE (diffusers AutoencoderKL) holds 248 tensors / 83,653,863 parameters: decoder + post_quant_conv
+    49,490,199, encoder + quant_conv 34,163,664.  The maps must give exactly that and round-trip; older checkpoints name
+    the attention projections query / key / value / proj_attn (some as 1x1 convolutions)."""
+    from tsd import checkpoint as ck
+    total = tensors = 0
+    for which, plist, want in (("decoder", spec.decoder_torch_params(), 49_490_199), ("encoder", spec.encoder_torch_params(), 34_163_664)):
+        assert sum(p.numel for p in plist if p.used) == want
+        P = {p.name: np.broadcast_to(np.float32(i + 1), p.shape) for i, p in enumerate(plist)}
+        sd = ck.params_to_diffusers_vae(P, which)
+        assert sum(int(np.prod(v.shape)) for v in sd.values()) == want
+        back = ck.diffusers_vae_to_params(sd, which)
+        assert {p.name for p in plist if p.used} <= set(back) <= {p.name for p in plist}
+        for name, a in back.items():
+            if "in_proj" not in name:
+                assert np.array_equal(a, P[name]), name
+        mod = (ck.VAE_DECODER_MODULES[4] if which == "decoder" else ck.VAE_ENCODER_MODULES[14])
+        old = dict(sd)
+        for new, legacy in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            old[f"{mod}.{legacy}.weight"] = np.asarray(old.pop(f"{mod}.{new}.weight"))[:, :, None, None]
+            old[f"{mod}.{legacy}.bias"] = old.pop(f"{mod}.{new}.bias")
+        legacy_back = ck.diffusers_vae_to_params(old, which)
+        for name in back:
+            assert np.array_equal(legacy_back[name], back[name]), name
+        total += want
+        tensors += len(sd)
+    assert total == 83_653_863 and tensors == 248

@@ -343,6 +343,32 @@ def test_torch_norm_unet_and_checkpoint_import(gpu_ctx, tsd_mod):
     d.model.close()
 
 
+def test_vae_torch_variants_and_import(gpu_ctx, tsd_mod):
+    """Extension (f-4): decoder / encoder with the trained VAE's norms (32 groups, per-channel affine) against the oracle's
+    torch-style restatement; a model loaded through the diffusers AutoencoderKL key map equals the directly initialised one."""
+    from tsd import checkpoint as ck
+    L = 8
+    lat = rng.normal(SEED, 590, 2 * 4 * L * L).reshape(2, 4, L, L)
+    dec = tsd_mod.Decoder(seed=SEED, variant="decoder_torch")
+    P = spec.init_params("decoder_torch", SEED)
+    out = dec.forward(lat)
+    ref = np.stack([models.decoder(P, lat[b], tn=True) for b in range(2)])
+    assert_close(out, ref, TOL_MODEL, None, "Decoder.forward, torch norms")
+    assert rel_l2(np.stack([models.decoder(P, lat[b]) for b in range(2)]), ref) > 0.05
+    loaded = ck.load_vae(ck.params_to_diffusers_vae(P, "decoder"), "decoder")
+    np.testing.assert_array_equal(loaded.forward(lat), out)
+    loaded.model.close(); dec.model.close()
+    img = rng.uniform(SEED, 591, 3 * 64 * 64, 1.0).reshape(3, 64, 64)
+    nz = rng.normal(SEED, 592, 4 * 8 * 8).reshape(4, 8, 8)
+    enc = tsd_mod.Encoder(seed=SEED, variant="encoder_torch")
+    Pe = spec.init_params("encoder_torch", SEED)
+    oe = enc.forward(img, nz)
+    assert_close(oe, models.encoder(Pe, img, nz, tn=True), TOL_MODEL, None, "Encoder.forward, torch norms")
+    loaded = ck.load_vae(ck.params_to_diffusers_vae(Pe, "encoder"), "encoder")
+    np.testing.assert_array_equal(loaded.forward(img, nz), oe)
+    loaded.model.close(); enc.model.close()
+
+
 def test_clip_torch_variant_matches_transformers(gpu_ctx, tsd_mod, tmp_path):
     """The product itself against an independent implementation: Hugging Face's CLIPTextModel (full 49408-token vocabulary,
     random weights including the LayerNorm affines; built in a subprocess, tests/hf_clip_reference.py) -> tsd.checkpoint
