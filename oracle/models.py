@@ -96,7 +96,7 @@ def unet_attention_block(P, prefix, x, context, n_head, n_embed, sem=DEFAULT, tn
     h = _ln(P, prefix + ".layer7", tok, sem, tn)                 # :136
     h = _lin(P, prefix + ".layer8", h)                           # :138
     a, gate = np.split(h, 2, axis=-1)                            # chunk(2,2) :138-140
-    h = a * ops.gelu_tanh(gate)                                  # :141
+    h = a * (ops.gelu_erf(gate) if tn else ops.gelu_tanh(gate))  # :141 (tn: torch's exact GELU)
     h = _lin(P, prefix + ".layer9", h)                           # :142
     tok = h + res                                                # :143
     h = ops.tokens_to_chw(tok, H, W)                             # :144-145

@@ -278,3 +278,15 @@ def layer_norm_torch(x, eps=1e-5, weight=None, bias=None):
     if bias is not None:
         y = y + np.asarray(bias, np.float64)
     return y.astype(np.float32)
+
+
+def gelu_erf(x):
+    """Exact GELU 0.5 x (1 + erf(x / sqrt 2)) = torch.nn.functional.gelu (extension; the reference's Gelu is the tanh form)."""
+    x64 = np.asarray(x, np.float64)
+    try:
+        from scipy.special import erf
+        e = erf(x64 / np.sqrt(2.0))
+    except ImportError:
+        from math import erf
+        e = np.vectorize(erf)(x64 / np.sqrt(2.0))
+    return (0.5 * x64 * (1.0 + e)).astype(np.float32)

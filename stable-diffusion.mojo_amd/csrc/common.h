@@ -196,6 +196,9 @@ int launch_time_embedding(tsd_ctx* ctx, const float* t_dev, float t_scalar, int 
 int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, const half_t* w, int ldw, const float* bias,
                         int N, int silu_in, float* y, int ldy);
 int launch_add_const_f32(tsd_ctx* ctx, float* dst, int64_t n, float c);
+// out[m][j] = x[m][2j] * gelu_erf(x[m][2j+1]) : GEGLU with torch's exact GELU on the interleaved (a, gate) pairs of an
+// un-fused geglu1 output (extension for real checkpoints; the reference's tanh form is fused into the GEMM epilogue)
+int launch_geglu_erf_f16(tsd_ctx* ctx, const half_t* x, int64_t rows, int n_out, half_t* out);
 int launch_fill_uniform(tsd_ctx* ctx, float* dst, int64_t n, uint64_t seed, uint64_t tensor_id, float bound);
 // weight packing: src fp32 reference layout -> packed fp16
 int launch_pack_conv(tsd_ctx* ctx, const float* src, int O, int I, int k, half_t* dst, int Opad, int Ipad);

@@ -193,7 +193,13 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   TSD_TRY(launch_layernorm(ctx, tok3, M, C, C, 1e-5f, ln, C, w.ln[2].w ? &w.ln[2] : nullptr));
   half_t* gg = arena_alloc<half_t>(ctx, M * 4 * C); CHECK_ALLOC(gg);
   a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S));
+  if (w.gelu_erf) {  // real-checkpoint extension: torch's exact GELU, as a pass of its own (the default path stays fused)
+    half_t* pre = arena_alloc<half_t>(ctx, M * 8 * C); CHECK_ALLOC(pre);
+    TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, 0, pre, 8 * C, nullptr, S));
+    TSD_TRY(launch_geglu_erf_f16(ctx, pre, M, 4 * C, gg));
+  } else {
+    TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S));
+  }
   half_t* tok4 = tok2;  // tok2 is dead after tok3
   CatSrc ag; ag.p0 = gg; ag.ld0 = 4 * C; ag.C0 = 4 * C;
   TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C, nullptr, S));

@@ -414,6 +414,33 @@ __global__ void k_fill_uniform(float* __restrict__ dst, int64_t n, uint64_t base
     dst[i] = __fmul_rn(v, bound);
   }
 }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.7071067811865476f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return 0.5f * x * (1.f + copysignf(erf_abs, x));
+}
+__global__ void k_geglu_erf(const half_t* __restrict__ x, int64_t n_pairs8, half_t* __restrict__ out) {
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pairs8; i += (int64_t)gridDim.x * blockDim.x) {
+    const h8v v = *(const h8v*)(x + i * 8);  // 4 (a, gate) pairs
+    h4v o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = (half_t)((float)v[2 * j] * gelu_erf_f((float)v[2 * j + 1]));
+    *(h4v*)(out + i * 4) = o;
+  }
+}
+int launch_geglu_erf_f16(tsd_ctx* ctx, const half_t* x, int64_t rows, int n_out, half_t* out) {
+  if (n_out % 4) TSD_FAIL(TSD_E_SHAPE, "geglu: output width %d must be a multiple of 4", n_out);
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t n = rows * (n_out / 4);
+  hipLaunchKernelGGL(k_geglu_erf, GRID1D(n, 256), dim3(256), 0, ctx->stream, x, n, out);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
 __global__ void k_add_const(float* __restrict__ dst, int64_t n, float c) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = __fadd_rn(dst[i], c);

@@ -220,6 +220,7 @@ int model_resolve(tsd_model* m) {
         a.kv_off = kvoff;
         if (kvoff == 0) { u.kproj_all = a.ca_k; u.vproj_all = a.ca_v; }
         kvoff += a.C;
+        a.gelu_erf = torch_norms;
         a.gn = aff(n + ".layer1"); a.ln[0] = aff(n + ".layer3"); a.ln[1] = aff(n + ".layer5"); a.ln[2] = aff(n + ".layer7");
       } else if (full && (l.kind == L_CONV || l.kind == L_UPCONV)) {
         u.conv[i] = model_conv(m, n);

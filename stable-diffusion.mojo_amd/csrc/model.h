@@ -63,6 +63,7 @@ struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   LinW sa_in, sa_out, ca_q, ca_k, ca_v, ca_out, geglu1, geglu2;
   int kv_off = 0;  // row offset of this block in the concatenated k_proj / v_proj tables
   NormAffine gn, ln[3];  // torch-norm extension (kind 6)
+  bool gelu_erf = false; // kind 6: exact GELU in the GEGLU gate (torch.nn.functional.gelu)
 };
 struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;

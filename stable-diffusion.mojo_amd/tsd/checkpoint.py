@@ -7,8 +7,8 @@ A diffusers-layout SD-1.x UNet (`unet/diffusion_pytorch_model.safetensors`: UNet
 parameters.  Pure host code: safetensors is parsed here (8-byte little-endian header length, JSON header, raw
 little-endian tensors; F32 / F16 / BF16), the tensors go through `tsd_model_set_param`.
 
-Known differences from diffusers numerics (both small): GEGLU uses the reference's tanh GELU (diffusers: erf), fp16
-storage of weights and activations with fp32 accumulation."""
+Numerics: fp16 storage of weights and activations with fp32 accumulation; the torch UNet kind uses torch's exact GELU
+in the GEGLU gate and per-channel affine norms with eps inside the root, like diffusers."""
 import json
 import struct
 

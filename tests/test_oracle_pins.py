@@ -106,6 +106,9 @@ def test_torch_style_norm_extension_matches_torch():
     lw, lb = 1.0 + 0.3 * randn(65, 16), 0.2 * randn(66, 16)
     np.testing.assert_allclose(ops.layer_norm_torch(t, 1e-5, lw, lb), F.layer_norm(T(t), (16,), T(lw), T(lb), eps=1e-5).numpy(),
                                rtol=1e-5, atol=1e-5)
+    g = randn(67, 4, 50) * 3.0
+    np.testing.assert_allclose(ops.gelu_erf(g), F.gelu(T(g)).numpy(), rtol=1e-5, atol=1e-6)
+    assert np.abs(ops.gelu_erf(g) - ops.gelu_tanh(g)).max() > 1e-4  # the reference's tanh form is a different function
     # and it differs from the reference's formula exactly where the two put eps
     assert not np.allclose(ops.group_norm_torch(x, 8, 1e-2), ops.group_norm(x, 8, 32, eps=1e-2), atol=1e-4)
 
