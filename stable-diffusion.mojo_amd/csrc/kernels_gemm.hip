@@ -460,7 +460,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   }
   // ---- epilogue ---------------------------------------------------------------------------
   const int g = lane >> 4;
-  const int epi = p.epi;
+  // epilogue terms that only one kernel family uses are compiled out of the other (launch_gemm rejects the combinations):
+  // GEGLU / per-row bias exist for dense GEMMs only, the time-embedding row vector / upsampled residual for conv3x3 only
+  const int epi = p.epi & (CONV ? ~(EPI_GEGLU | EPI_BIAS_M) : ~(EPI_ROWVEC | EPI_RES_UPS));
   const int nb = n0 + wn * BNw + g * (4 * FN);
 
   // Coalesced path (every tile shape but the thin N <= 16 one, N % 8 == 0).  The MFMA layout leaves each lane with
@@ -1062,6 +1064,8 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   if (a.K % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: K=%d must be a multiple of 64 (pad at pack time)", a.K);
   if (a.N % 4) TSD_FAIL(TSD_E_SHAPE, "gemm: N=%d must be a multiple of 4", a.N);
   if ((a.epi & EPI_GEGLU) && (a.N % 8)) TSD_FAIL(TSD_E_SHAPE, "gemm: GEGLU needs N %% 8 == 0");
+  if (a.conv ? (a.epi & (EPI_GEGLU | EPI_BIAS_M)) : (a.epi & (EPI_ROWVEC | EPI_RES_UPS)))
+    TSD_FAIL(TSD_E_ARG, "gemm: epilogue flags 0x%x are not available for %s", a.epi, a.conv ? "conv3x3" : "dense GEMMs");
   if (a.conv) {
     if (a.Cin % 64 || a.K != 9 * a.Cin) TSD_FAIL(TSD_E_SHAPE, "conv3x3: Cin=%d K=%d", a.Cin, a.K);
     if (a.batch != 1) TSD_FAIL(TSD_E_ARG, "conv3x3: batch is folded into M");
