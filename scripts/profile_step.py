@@ -11,9 +11,12 @@ what = os.environ.get("WHAT", "unet")
 ctx = tsd.default_context()
 d = tsd.Diffusion(seed=1234, variant=os.environ.get("VARIANT", "diffusion"))
 dec = tsd.Decoder(seed=1234) if what == "dec" else None
+enc = tsd.Encoder(seed=1234) if what == "enc" else None
 lat = rng.normal(1, 1, B*4*L*L).reshape(B,4,L,L); cx = rng.normal(1, 2, B*T*768).reshape(B,T,768)
 s = tsd.Session(d.model, dec.model if dec else None, B, L, T); s.set_schedule(1000, 50, 0); s.upload(lat, cx, None, None)
-run = (lambda: s.decode()) if what == "dec" else (lambda: s.step(1))
+if what == "enc":
+    img = rng.uniform(1, 7, B*3*64*L*L, 1.0).reshape(B, 3, 8*L, 8*L); nz = rng.normal(1, 8, B*4*L*L).reshape(B, 4, L, L)
+run = (lambda: s.decode()) if what == "dec" else ((lambda: enc.forward(img, nz)) if what == "enc" else (lambda: s.step(1)))
 for _ in range(3): run()
 ctx.synchronize()
 ctx.profile_begin(); run(); recs = ctx.profile_records(); ctx.profile_end()

@@ -71,7 +71,7 @@ struct tsd_ctx {
 
 enum KernelClass : int {
   KC_GEMM = 0, KC_CONV = 1, KC_ATTN = 2, KC_GROUPNORM = 3, KC_LAYERNORM = 4, KC_SMALL_LINEAR = 5,
-  KC_ELEMENTWISE = 6, KC_SOFTMAX = 7, KC_COUNT = 8
+  KC_ELEMENTWISE = 6, KC_SOFTMAX = 7, KC_CHAIN = 8, KC_COUNT = 9
 };
 // RAII: records a start/stop event pair around the launches in its scope when profiling is on
 struct ProfScope {
@@ -241,4 +241,23 @@ struct AttnArgs {
   float scale = 1.f;
 };
 bool attn_fused_supported(int d);
+
+// fused row-local tail of `Unet_Attention_Block.forward` (kernels_chain.hip): self-attention out_proj + residual, LayerNorm,
+// cross-attention over the projected context, LayerNorm, GEGLU feed-forward, 1x1 conv_out + long residual in ONE kernel.
+struct AttnTailArgs {
+  const half_t* ao = nullptr; int ld_ao = 0;    // self-attention output [M][C]
+  const half_t* tok = nullptr; int ld_tok = 0;  // first residual (conv_in output)
+  const half_t* x = nullptr; int ld_x = 0;      // block input (long residual)
+  half_t* out = nullptr; int ld_out = 0;
+  const half_t *Wso = nullptr, *Wq = nullptr, *Wco = nullptr, *W1 = nullptr, *W2 = nullptr, *Wout = nullptr;
+  int ldw_so = 0, ldw_q = 0, ldw_co = 0, ldw_1 = 0, ldw_2 = 0, ldw_out = 0;
+  const float *bso = nullptr, *bco = nullptr, *b1 = nullptr, *b2 = nullptr, *bout = nullptr;
+  const half_t* Kc = nullptr; int ldk = 0; int64_t sK = 0;
+  const half_t* Vt = nullptr; int ldvt = 0; int64_t sVt = 0;
+  int C = 0, d = 0, heads = 0, T = 0, S = 0; int64_t M = 0;
+  float scale = 1.f, eps = 1e-5f;
+  float* gn_part = nullptr; int gn_nslab = 0;  // GroupNorm(32) statistics of the output, one slab per 32 rows
+};
+bool attn_tail_supported(int C, int d, int heads, int T, int64_t M, int S);
+int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a);
 int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a);

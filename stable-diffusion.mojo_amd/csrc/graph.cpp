@@ -154,14 +154,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   fa.O = ao; fa.ldo = C; fa.sO = (int64_t)S * C;
   fa.B = B; fa.H = Hh; fa.d = d; fa.Sq = S; fa.Sk = S; fa.scale = scale;
   TSD_TRY(launch_flash_attention(ctx, fa));
-  half_t* tok2 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok2);
-  a.p0 = ao;
-  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C, nullptr, S));
-  // ---- cross attention (:129-133) ----
-  TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C, w.ln[1].w ? &w.ln[1] : nullptr));
-  half_t* q = qk;  // reuse
-  a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C, nullptr, S));
+  // context keys / values of this block: projected once for all blocks by g_unet_forward, or here (block-level entry)
   CtxKV kv;
   if (pre) kv = *pre;  // context K / V^T of all nine blocks were projected in two batched GEMMs (g_unet_forward)
   else {
@@ -181,6 +174,39 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     v.C = vtc; v.ldc = Tp; v.sC = (int64_t)C * Tp;
     TSD_TRY(launch_gemm(ctx, v));
   }
+  // Everything after the self-attention core is local to a token row: at the 64x64 level (C = 320) it runs as ONE kernel
+  // (kernels_chain.hip) instead of nine launches.  Reference norms / tanh-GELU only (the torch-norm extension keeps the
+  // op-by-op path).
+  const bool plain_norms = !w.ln[1].w && !w.ln[1].b && !w.ln[2].w && !w.ln[2].b && !w.gelu_erf;
+  if (plain_norms && attn_tail_supported(C, d, Hh, T, M, S) && w.sa_out.b && w.ca_out.b && w.geglu1.b && w.geglu2.b &&
+      w.conv_out.b && !w.ca_q.b && w.sa_out.Kpad == C && w.ca_q.Kpad == C && w.ca_out.Kpad == C && w.geglu1.Kpad == C &&
+      w.geglu2.Kpad == 4 * C && w.conv_out.Ipad == C) {
+    AttnTailArgs ta;
+    ta.ao = ao; ta.ld_ao = C; ta.tok = tok; ta.ld_tok = C; ta.x = x.p; ta.ld_x = x.ld; ta.out = out.p; ta.ld_out = out.ld;
+    ta.Wso = w.sa_out.w; ta.ldw_so = w.sa_out.Kpad; ta.bso = w.sa_out.b;
+    ta.Wq = w.ca_q.w; ta.ldw_q = w.ca_q.Kpad;
+    ta.Wco = w.ca_out.w; ta.ldw_co = w.ca_out.Kpad; ta.bco = w.ca_out.b;
+    ta.W1 = w.geglu1.w; ta.ldw_1 = w.geglu1.Kpad; ta.b1 = w.geglu1.b;
+    ta.W2 = w.geglu2.w; ta.ldw_2 = w.geglu2.Kpad; ta.b2 = w.geglu2.b;
+    ta.Wout = w.conv_out.w; ta.ldw_out = w.conv_out.Ipad; ta.bout = w.conv_out.b;
+    ta.Kc = kv.K; ta.ldk = kv.ldk; ta.sK = kv.sK; ta.Vt = kv.Vt; ta.ldvt = kv.ldvt; ta.sVt = kv.sVt;
+    ta.C = C; ta.d = d; ta.heads = Hh; ta.T = T; ta.S = S; ta.M = M; ta.scale = scale; ta.eps = 1e-5f;
+    if (out.gn_buf && out.gn_groups == 32) {  // statistics for the next block's GroupNorm(32): one slab per 32 rows
+      ta.gn_part = out.gn_buf; ta.gn_nslab = S / 32;
+      out.gn_part = out.gn_buf; out.gn_nslab = S / 32;
+    }
+    TSD_TRY(launch_attn_tail(ctx, ta));
+    ctx->arena.release(mark);
+    return TSD_OK;
+  }
+  half_t* tok2 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok2);
+  a.p0 = ao;
+  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C, nullptr, S));
+  // ---- cross attention (:129-133) ----
+  TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C, w.ln[1].w ? &w.ln[1] : nullptr));
+  half_t* q = qk;  // reuse
+  a.p0 = ln;
+  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C, nullptr, S));
   fa.Q = q; fa.ldq = C; fa.sQ = (int64_t)S * C;
   fa.K = kv.K; fa.ldk = kv.ldk; fa.sK = kv.sK;
   fa.Vt = kv.Vt; fa.ldvt = kv.ldvt; fa.sVt = kv.sVt;

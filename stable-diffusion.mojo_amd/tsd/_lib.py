@@ -179,16 +179,17 @@ class Context:
         return ms.value
 
     KERNEL_CLASSES = ("gemm", "conv3x3", "flash_attention", "groupnorm", "layernorm", "small_linear", "elementwise",
-                      "softmax")
+                      "softmax", "attn_tail_chain")
 
     def profile_begin(self):
         check(lib().tsd_ctx_profile_begin(self.h))
 
     def profile_end(self):
         """{class: (total_ms, launches)} measured with hipEvents on this context's stream."""
-        ms = (C.c_float * 8)()
-        n = (C.c_int * 8)()
-        check(lib().tsd_ctx_profile_end(self.h, ms, n, 8))
+        nc = len(self.KERNEL_CLASSES)
+        ms = (C.c_float * nc)()
+        n = (C.c_int * nc)()
+        check(lib().tsd_ctx_profile_end(self.h, ms, n, nc))
         return {k: (ms[i], n[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
     def profile_records(self, cap=8192):
