@@ -249,8 +249,7 @@ struct AttnTailArgs {
   const half_t* tok = nullptr; int ld_tok = 0;  // first residual (conv_in output)
   const half_t* x = nullptr; int ld_x = 0;      // block input (long residual)
   half_t* out = nullptr; int ld_out = 0;
-  const half_t *Wso = nullptr, *Wq = nullptr, *Wco = nullptr, *W1 = nullptr, *W2 = nullptr, *Wout = nullptr;
-  int ldw_so = 0, ldw_q = 0, ldw_co = 0, ldw_1 = 0, ldw_2 = 0, ldw_out = 0;
+  const half_t* wstream = nullptr;  // launch_attn_tail_pack() image of sa_out, ca_q, ca_out, geglu1, geglu2, conv_out
   const float *bso = nullptr, *bco = nullptr, *b1 = nullptr, *b2 = nullptr, *bout = nullptr;
   const half_t* Kc = nullptr; int ldk = 0; int64_t sK = 0;
   const half_t* Vt = nullptr; int ldvt = 0; int64_t sVt = 0;
@@ -260,4 +259,7 @@ struct AttnTailArgs {
 };
 bool attn_tail_supported(int C, int d, int heads, int T, int64_t M, int S);
 int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a);
+size_t attn_tail_stream_bytes();
+int launch_attn_tail_pack(tsd_ctx* ctx, const half_t* Wso, int ld_so, const half_t* Wq, int ld_q, const half_t* Wco, int ld_co,
+                          const half_t* W1, int ld_1, const half_t* W2, int ld_2, const half_t* Wout, int ld_out, half_t* dst);
 int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a);

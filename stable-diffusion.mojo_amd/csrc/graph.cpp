@@ -177,18 +177,20 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   // Everything after the self-attention core is local to a token row: at the 64x64 level (C = 320) it runs as ONE kernel
   // (kernels_chain.hip) instead of nine launches.  Reference norms / tanh-GELU only (the torch-norm extension keeps the
   // op-by-op path).
-  const bool plain_norms = !w.ln[1].w && !w.ln[1].b && !w.ln[2].w && !w.ln[2].b && !w.gelu_erf;
-  if (plain_norms && attn_tail_supported(C, d, Hh, T, M, S) && w.sa_out.b && w.ca_out.b && w.geglu1.b && w.geglu2.b &&
-      w.conv_out.b && !w.ca_q.b && w.sa_out.Kpad == C && w.ca_q.Kpad == C && w.ca_out.Kpad == C && w.geglu1.Kpad == C &&
-      w.geglu2.Kpad == 4 * C && w.conv_out.Ipad == C) {
+  // The block-level entry (no model) packs the stream into the workspace on the fly.
+  const half_t* tail_stream = w.tail_stream;
+  const bool tail_ok = attn_tail_supported(C, d, Hh, T, M, S) && attn_tail_weights_ok(w);
+  if (tail_ok && !tail_stream && !pre) {
+    half_t* ts = arena_alloc<half_t>(ctx, (int64_t)attn_tail_stream_bytes() / 2); CHECK_ALLOC(ts);
+    TSD_TRY(launch_attn_tail_pack(ctx, w.sa_out.w, w.sa_out.Kpad, w.ca_q.w, w.ca_q.Kpad, w.ca_out.w, w.ca_out.Kpad, w.geglu1.w,
+                                  w.geglu1.Kpad, w.geglu2.w, w.geglu2.Kpad, w.conv_out.w, w.conv_out.Ipad, ts));
+    tail_stream = ts;
+  }
+  if (tail_ok && tail_stream) {
     AttnTailArgs ta;
     ta.ao = ao; ta.ld_ao = C; ta.tok = tok; ta.ld_tok = C; ta.x = x.p; ta.ld_x = x.ld; ta.out = out.p; ta.ld_out = out.ld;
-    ta.Wso = w.sa_out.w; ta.ldw_so = w.sa_out.Kpad; ta.bso = w.sa_out.b;
-    ta.Wq = w.ca_q.w; ta.ldw_q = w.ca_q.Kpad;
-    ta.Wco = w.ca_out.w; ta.ldw_co = w.ca_out.Kpad; ta.bco = w.ca_out.b;
-    ta.W1 = w.geglu1.w; ta.ldw_1 = w.geglu1.Kpad; ta.b1 = w.geglu1.b;
-    ta.W2 = w.geglu2.w; ta.ldw_2 = w.geglu2.Kpad; ta.b2 = w.geglu2.b;
-    ta.Wout = w.conv_out.w; ta.ldw_out = w.conv_out.Ipad; ta.bout = w.conv_out.b;
+    ta.wstream = tail_stream;
+    ta.bso = w.sa_out.b; ta.bco = w.ca_out.b; ta.b1 = w.geglu1.b; ta.b2 = w.geglu2.b; ta.bout = w.conv_out.b;
     ta.Kc = kv.K; ta.ldk = kv.ldk; ta.sK = kv.sK; ta.Vt = kv.Vt; ta.ldvt = kv.ldvt; ta.sVt = kv.sVt;
     ta.C = C; ta.d = d; ta.heads = Hh; ta.T = T; ta.S = S; ta.M = M; ta.scale = scale; ta.eps = 1e-5f;
     if (out.gn_buf && out.gn_groups == 32) {  // statistics for the next block's GroupNorm(32): one slab per 32 rows

@@ -11,17 +11,21 @@
 //     terms and the residual adds are lane-local);
 //   * the A operand of every GEMM (ao, LN(T), q, attention output, GEGLU activations, tok4) is an fp16 tile in LDS in the
 //     swizzled 128-B-row layout the MFMA fragment reads want, written straight from the accumulator registers;
-//   * the weights of all stages form ONE stream of [160 rows][64 k] half-tiles DMA'd (buffer_load ... lds) through a
-//     5-slot LDS ring, three half-tiles ahead of the MFMAs and across stage boundaries, behind counted s_waitcnt vmcnt;
+//   * the weights of all stages are PRE-PACKED (launch_attn_tail_pack, once per model) into one stream of [rows][32 k]
+//     tiles that are byte images of their LDS layout (row permutation and bank swizzle baked in): staging a tile is a
+//     linear 20 KB buffer_load ... lds copy with no per-lane address math, and the stream runs four tiles ahead of the
+//     MFMAs through a 5-slot LDS ring, across stage boundaries, behind counted s_waitcnt vmcnt;
 //   * the 77 context keys / values of the sample (projected once per step) are staged in the ring region; the scores
 //     never leave registers: swapped-operand QK^T leaves each lane with the scores of ONE query row, and the key -> MFMA
 //     row permutation makes the fp16 probabilities the A fragments of the P.V MFMAs without any data movement;
-//   * LayerNorm statistics are an in-lane sum + two lane shuffles + one LDS exchange between the two column waves;
+//   * LayerNorm statistics are an in-lane sum + two lane shuffles + one LDS exchange between the two column waves
+//     (per-wave mean / M2 merged exactly);
 //   * the output's GroupNorm statistics (for the next residual block) come from the rounded values in registers.
 // MFMA: v_mfma_f32_16x16x32_f16 with swapped operands (D = Wfrag x Afrag^T), 4 waves as 2(M) x 2(N), a wave tile is
-// 32 rows x 160 columns (FM = 2, FN = 10), one wave per SIMD, pinned issue order as in kernels_gemm.hip.
+// 32 rows x 160 columns (FM = 2, FN = 10), one wave per SIMD.
 #include <math.h>
 #include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -36,11 +40,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct TailK {
   const half_t* ao; const half_t* tok; const half_t* x; half_t* out;
   int ld_ao, ld_tok, ld_x, ld_out;
-  const half_t *Wso, *Wq, *Wco, *W1, *W2, *Wout;
+  const half_t* wstream;                      // launch_attn_tail_pack() image of Wso, Wq, Wco, W1, W2, Wout
   const float *bso, *bco, *b1, *b2, *bout;
   const half_t* Kc; int ldk; long long sK;    // projected context keys   [B][>=T rows][ldk], this block's columns
   const half_t* Vt; int ldvt; long long sVt;  // projected context values [B][C rows][ldvt]  (key-contiguous)
-  int T;                                      // valid keys (<= 96)
+  int T;                                      // valid keys (<= 80)
   int M, S;                                   // token rows, rows per sample (S % 64 == 0)
   float qscale;                               // softmax scale * log2(e), folded into q
   float eps;
@@ -51,10 +55,18 @@ namespace {
 constexpr int C = 320, BM = 64;
 constexpr int A_OFF = 0, A_KT = 8192;                 // A tile: 5 k-tiles x [64 rows][128 B]
 constexpr int ACT_OFF = 40960;                        // GEGLU activations: 2 k-tiles x [64][128 B]
-constexpr int RING_OFF = ACT_OFF + 16384, HSLOT = 20480;  // 5 half-slots of [160 rows][128 B]
-constexpr int SCR_OFF = RING_OFF + 5 * HSLOT;         // LayerNorm exchange: [2][64 rows][2 column waves] floats
+constexpr int RING_OFF = ACT_OFF + 16384, SLOT = 20480, NSLOT = 5;  // ring of [2 halves][160 rows][64 B] weight tiles
+constexpr int SCR_OFF = RING_OFF + NSLOT * SLOT;      // LayerNorm exchange: [64 rows][2 column waves] x (mean, M2)
 constexpr int LDS_BYTES = SCR_OFF + 1024;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
+// the weight stream (bytes): tiles of 32 k.  Full tiles hold 320 rows (20480 B), GEGLU-1 tiles 256 rows (16384 B).
+constexpr int TILE_FULL = 20480, TILE_G1 = 16384;
+constexpr int SEG0_TILES = 20;                                    // Wso (10), Wq (10)
+constexpr int SEG0_BYTES = SEG0_TILES * TILE_FULL;
+constexpr int FFN_CHUNK_BYTES = 10 * TILE_G1 + 4 * TILE_FULL;     // GEGLU-1 chunk (K = 320), GEGLU-2 chunk (K = 128)
+constexpr int SEG1_TILES = 10 + 10 * 14 + 10;                     // Wco, 10 x (W1 chunk, W2 chunk), Wout
+constexpr int SEG1_BYTES = 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES + 10 * TILE_FULL;
+constexpr int STREAM_BYTES = SEG0_BYTES + SEG1_BYTES;
 
 __device__ __forceinline__ float gelu_tanh_c(float x) {  // helpers/utils.mojo:1914 (see kernels_gemm.hip)
   const float c2 = -2.f * 0.7978845608028654f * 1.4426950408889634f;
@@ -68,7 +80,52 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+// bank swizzle of the 64-B weight rows: 16-B chunk c of LDS row rho sits at chunk c ^ wswz(rho) (conflict-free
+// ds_read_b128 across the instruction's four 16-lane service groups)
+__host__ __device__ __forceinline__ int wswz(int rho) { return 3 * ((rho >> 2) & 1); }
 }  // namespace
+
+// ---- weight pre-packing: reference-layout fp16 matrices -> the kernel's tile stream --------------------------------
+// One thread per 16-B chunk of the stream.  Tile t of a matrix W[N][ldw] (k columns 32t .. 32t+31, offset kofs):
+//   image byte  half*HB + rho*64 + pc*16  <-  W[n(half, rho)][kofs + 32t + 8*(pc ^ wswz(rho)) .. +8]
+// with n(half, rho) = half*NH + (ii>>2)*(NH/4) + fn*4 + (ii&3), fn = rho>>4, ii = rho&15 (NH = rows per half): output
+// lane (g, r) of fragment b then owns column half*NH + g*(NH/4) + b*4 + r - NH/4 consecutive columns per lane.
+struct PackSrc { const half_t* w; int ldw; };
+__global__ void k_attn_tail_pack(PackSrc so, PackSrc q, PackSrc co, PackSrc w1, PackSrc w2, PackSrc wo, half_t* dst) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;  // 16-B chunk index in the stream
+  if (ci >= STREAM_BYTES / 16) return;
+  int byte = ci * 16;
+  const half_t* W; int ldw, row0 = 0, kofs = 0, NH, t;
+  if (byte < SEG0_BYTES) {
+    const int ti = byte / TILE_FULL; byte -= ti * TILE_FULL;
+    W = ti < 10 ? so.w : q.w; ldw = ti < 10 ? so.ldw : q.ldw; t = ti % 10; NH = 160;
+  } else {
+    byte -= SEG0_BYTES;
+    if (byte < 10 * TILE_FULL) { t = byte / TILE_FULL; byte -= t * TILE_FULL; W = co.w; ldw = co.ldw; NH = 160; }
+    else if (byte < 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES) {
+      byte -= 10 * TILE_FULL;
+      const int jc = byte / FFN_CHUNK_BYTES; byte -= jc * FFN_CHUNK_BYTES;
+      if (byte < 10 * TILE_G1) { t = byte / TILE_G1; byte -= t * TILE_G1; W = w1.w; ldw = w1.ldw; row0 = jc * 256; NH = 128; }
+      else { byte -= 10 * TILE_G1; t = byte / TILE_FULL; byte -= t * TILE_FULL; W = w2.w; ldw = w2.ldw; kofs = jc * 128; NH = 160; }
+    } else {
+      byte -= 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES;
+      t = byte / TILE_FULL; byte -= t * TILE_FULL; W = wo.w; ldw = wo.ldw; NH = 160;
+    }
+  }
+  const int half = byte / (NH * 64), rb = byte - half * NH * 64;
+  const int rho = rb >> 6, pc = (rb >> 4) & 3;
+  const int fn = rho >> 4, ii = rho & 15;
+  const int n = row0 + half * NH + (ii >> 2) * (NH / 4) + fn * 4 + (ii & 3);
+  const int k = kofs + 32 * t + 8 * (pc ^ wswz(rho));
+  *(h8*)(dst + (size_t)ci * 8) = *(const h8*)(W + (size_t)n * ldw + k);
+}
+
+#ifdef TSD_CHAIN_TS
+__device__ unsigned long long g_chain_ts[1024 * 16];  // per block: s_memtime at the phase marks (experiment build only)
+#define CTS(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_chain_ts[blockIdx.x * 16 + (i)] = (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CTS(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,148 +133,156 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int rsel = lane & 15, key = lane & 7, g = lane >> 4;
-  const int lrow = lane >> 3, cch = (lane & 7) ^ lrow;  // DMA: LDS row within an 8-row piece, logical 16-B chunk fetched
+  const int lrow = lane >> 3, cch = (lane & 7) ^ lrow;  // gather DMA: LDS row within an 8-row piece, logical 16-B chunk fetched
   const int m0 = blockIdx.x * BM;
   const int bsmp = m0 / p.S;
-
-  // ---- per-lane DMA offsets of the three weight-tile shapes ------------------------------------------------------
-  // LDS row rho of a half-tile holds weight row n(rho) such that output lane (g, r) of fragment b is column
-  // g*4*FN + b*4 + r of the half: every lane ends up with 4*FN CONSECUTIVE columns of its row.
-  unsigned vo320[2][5], vo1280[2][5], vo256[2][5];
-#pragma unroll
-  for (int hf = 0; hf < 2; hf++)
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const int rho = (wave + 4 * i) * 8 + lrow, fn = rho >> 4, ii = rho & 15;
-      const int n0 = hf * 160 + (ii >> 2) * 40 + fn * 4 + (ii & 3);
-      vo320[hf][i] = (unsigned)(n0 * 320 + cch * 8) * 2;
-      vo1280[hf][i] = (unsigned)(n0 * 1280 + cch * 8) * 2;
-      const int n1 = hf * 128 + (ii >> 2) * 32 + fn * 4 + (ii & 3);
-      vo256[hf][i] = rho < 128 ? (unsigned)(n1 * 320 + cch * 8) * 2 : PAD_OFF;
-    }
+  CTS(0);
+  CTS(14);
 
   // ---- the weight stream ---------------------------------------------------------------------------------------
-  struct WT { rsrc_t r; unsigned soff; int vset; };
-  auto mk = [&](const half_t* base, unsigned soff, int vset, bool live) {
-    WT t;
-    t.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(base), 0, live ? 0x7ffffff0 : 0, 0x00020000);
-    t.soff = soff; t.vset = vset;
-    return t;
-  };
-  // segment 0: out_proj of the self-attention, q_proj.  segment 1: cross out_proj, 10 x (GEGLU-1 chunk, GEGLU-2 chunk), conv_out.
-  auto tile_at = [&](int seg, int gi) {
-    if (seg == 0) {
-      if (gi < 5) return mk(p.Wso, gi * 128, 0, true);
-      if (gi < 10) return mk(p.Wq, (gi - 5) * 128, 0, true);
-      return mk(p.Wso, 0, 0, false);
+  // byte offset / size class of tile gi of a segment (wave-uniform)
+  auto tile_off = [&](int seg, int gi, bool& g1, bool& live) {
+    g1 = false; live = true;
+    if (seg == 0) { live = gi < SEG0_TILES; return gi * TILE_FULL; }
+    if (gi < 10) return SEG0_BYTES + gi * TILE_FULL;
+    if (gi < 150) {
+      const int q = gi - 10, jc = q / 14, r = q - 14 * jc;
+      const int base = SEG0_BYTES + 10 * TILE_FULL + jc * FFN_CHUNK_BYTES;
+      if (r < 10) { g1 = true; return base + r * TILE_G1; }
+      return base + 10 * TILE_G1 + (r - 10) * TILE_FULL;
     }
-    if (gi < 5) return mk(p.Wco, gi * 128, 0, true);
-    if (gi < 75) {
-      const int q = gi - 5, j = q / 7, r = q - 7 * j;
-      if (r < 5) return mk(p.W1 + (long long)j * 256 * 320, r * 128, 1, true);
-      return mk(p.W2, (unsigned)(j * 128 + (r - 5) * 64) * 2, 2, true);
-    }
-    if (gi < 80) return mk(p.Wout, (gi - 75) * 128, 0, true);
-    return mk(p.Wso, 0, 0, false);
+    live = gi < SEG1_TILES;
+    return SEG0_BYTES + 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES + (gi - 150) * TILE_FULL;
   };
-  auto piece = [&](const WT& t, int hf, int slot, int i) {
-    const unsigned v0 = hf ? vo320[1][i] : vo320[0][i], v1 = hf ? vo256[1][i] : vo256[0][i], v2 = hf ? vo1280[1][i] : vo1280[0][i];
-    const unsigned v = t.vset == 0 ? v0 : (t.vset == 1 ? v1 : v2);
-    blds16(t.r, v, t.soff, smem + RING_OFF + slot * HSLOT + (wave + 4 * i) * 1024);
+  const rsrc_t rw = make_rsrc(p.wstream, STREAM_BYTES), rdead = make_rsrc(p.wstream, 0);
+  const unsigned lane16 = lane * 16;
+  // piece i (of 5 per wave) of tile gi -> ring slot: 1-KiB wave-instruction number wave + 4*i of the tile image
+  auto piece = [&](int off, bool g1, bool live, int slot, int i) {
+    const int j = wave + 4 * i;
+    const bool on = live && !(g1 && j >= 16);
+    blds16(on ? rw : rdead, lane16, (unsigned)(off + j * 1024), smem + RING_OFF + slot * SLOT + j * 1024);
   };
-  int gt = 0, sl = 0;  // tile counter within the segment ; ring slot of the current tile's first half
-  WT saved;            // descriptor of tile gt + 1
+  int gt = 0, sl = 0;  // tile counter within the segment ; ring slot of tile gt
   auto seg_begin = [&](int seg) {
     gt = 0; sl = 0;
-    const WT t0 = tile_at(seg, 0);
-    saved = tile_at(seg, 1);
 #pragma unroll
-    for (int i = 0; i < 5; i++) piece(t0, 0, 0, i);
+    for (int t = 0; t < 4; t++) {
+      bool g1, live;
+      const int off = tile_off(seg, t, g1, live);
 #pragma unroll
-    for (int i = 0; i < 5; i++) piece(t0, 1, 1, i);
-#pragma unroll
-    for (int i = 0; i < 5; i++) piece(saved, 0, 2, i);
+      for (int i = 0; i < 5; i++) if (!(g1 && i == 4)) piece(off, g1, live, t, i);
+    }
   };
 
-  // ---- one GEMM stage: acc[2][FN] = Atile[64][nkt*64] . W^T over the next nkt tiles of the stream -------------------
-  const int a_rd = (wm * 32 + rsel) * 128, w_rd = rsel * 128;
-  auto gemm = [&](auto fn_c, auto seg_c, f4 (&acc)[2][10], int a_base, int nkt) {
-    constexpr int FN = decltype(fn_c)::value, SEG = decltype(seg_c)::value;
+  // ---- one GEMM stage: acc[2][FN] (+)= Atile[64][nk*32] . W^T over the next nk tiles of the stream -----------------
+  // EXTRA = VMEM loads the caller issued since the last DMA piece (bias / residual prefetch): they are younger than the
+  // tiles the first wait is for.
+  const int a_rd = (wm * 32 + rsel) * 128;
+  const int w_rd = rsel * 64 + ((g ^ wswz(rsel)) << 4);
+  auto gemm = [&](auto fn_c, auto seg_c, auto zero_c, auto extra_c, f4 (&acc)[2][10], int a_base, int nk) {
+    constexpr int FN = decltype(fn_c)::value, SEG = decltype(seg_c)::value, EXTRA = decltype(extra_c)::value;
+    constexpr bool ZERO = decltype(zero_c)::value;
+    if (ZERO) {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+      for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int b = 0; b < FN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nkt; kt++) {
-      wait_vm<5>();                     // both halves of tile gt have landed (one younger half-tile stays in flight)
-      __builtin_amdgcn_s_barrier();     // ... for every wave; the slots of tile gt-1 are free
-      asm volatile("" ::: "memory");
-      const char* sA = smem + a_base + kt * A_KT;
-      int ws = sl + wn; ws = ws >= 5 ? ws - 5 : ws;
-      const char* sW = smem + RING_OFF + ws * HSLOT;
-      h8 af[2][2], wf[2][FN];
+        for (int b = 0; b < FN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // Software pipeline over the tiles (one wave per SIMD: nobody else hides the LDS latency): the fragment reads of
+    // tile t are issued right after its barrier and land while the MFMAs of tile t-1 run from the other register set.
+    h8 afA[2], wfA[FN], afB[2], wfB[FN];
+    // One pipeline step = barrier of tile gt, then the 2*FN MFMAs of tile gt-1 (register set p*) with the 2 + FN fragment
+    // reads of tile gt (into set n*) and the wave's DMA instructions for tile gt+4 spread between them: a burst of 48
+    // ds_read_b128 from the four waves right after the barrier would hold the LDS (and every wave's issue) for ~200 cycles.
+    auto step = [&](int kt, h8 (&af)[2], h8 (&wf)[FN], const h8 (&paf)[2], const h8 (&pwf)[FN], bool have_prev, bool have_next) {
+      bool g1 = false, live = false;
+      int off = 0, s4 = 0;
+      const char *sA = smem, *sW = smem;
+      if (have_next) {
+        // tile gt has landed: the three younger tiles (and the caller's EXTRA loads, which sit between tile gt+3 and tile
+        // gt+4 of the stage's first tile in the queue) may stay in flight
+        int younger = EXTRA > 0 && kt < 4 ? EXTRA : 0;
 #pragma unroll
-      for (int kk = 0; kk < 2; kk++) {
-        const int coff = ((kk * 4 + g) ^ key) << 4;
-#pragma unroll
-        for (int b = 0; b < FN; b++) wf[kk][b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
-#pragma unroll
-        for (int a = 0; a < 2; a++) af[kk][a] = *(const h8*)(sA + a_rd + a * 2048 + coff);
+        for (int d = 1; d <= 3; d++) { bool yg1, ylive; tile_off(SEG, gt + d, yg1, ylive); younger += yg1 ? 4 : 5; }
+        switch (younger - (EXTRA > 0 && kt < 4 ? EXTRA : 0)) {
+          case 12: if (EXTRA > 0 && kt < 4) wait_vm<12 + EXTRA>(); else wait_vm<12>(); break;
+          case 13: if (EXTRA > 0 && kt < 4) wait_vm<13 + EXTRA>(); else wait_vm<13>(); break;
+          case 14: if (EXTRA > 0 && kt < 4) wait_vm<14 + EXTRA>(); else wait_vm<14>(); break;
+          default: if (EXTRA > 0 && kt < 4) wait_vm<15 + EXTRA>(); else wait_vm<15>(); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile gt-1 are complete: its slot may be refilled
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        sA = smem + a_base + (kt >> 1) * A_KT + a_rd + ((((kt & 1) * 4 + g) ^ key) << 4);
+        sW = smem + RING_OFF + sl * SLOT + wn * (FN == 10 ? 10240 : 8192) + w_rd;
+        off = tile_off(SEG, gt + 4, g1, live);
+        s4 = sl == 0 ? 4 : sl - 1;  // (sl + 4) % 5: the slot tile gt-1 just left
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const WT d1 = saved, d2 = tile_at(SEG, gt + 2);
-      int s3 = sl + 3; s3 = s3 >= 5 ? s3 - 5 : s3;
-      int s4 = sl + 4; s4 = s4 >= 5 ? s4 - 5 : s4;
-      constexpr int NM = 4 * FN, GAP = NM / 11;
+      constexpr int NM = 2 * FN, NR = 2 + FN;
+      if (!have_prev) {  // first tile of the stage: nothing to multiply yet
 #pragma unroll
-      for (int q = 0; q < NM; q++) {
-        const int kk = q / (2 * FN), a = (q / FN) & 1, b = q % FN;
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
-        if ((q + 1) % GAP == 0 && (q + 1) / GAP - 1 < 10) {
-          const int i = (q + 1) / GAP - 1;
-          __builtin_amdgcn_sched_barrier(0);
-          if (i < 5) piece(d1, 1, s3, i); else piece(d2, 0, s4, i - 5);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int a = 0; a < 2; a++) af[a] = *(const h8*)(sA + a * 2048);
+#pragma unroll
+        for (int b = 0; b < FN; b++) wf[b] = *(const h8*)(sW + b * 1024);
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (!(g1 && i == 4)) piece(off, g1, live, s4, i);
+      } else {
+        int ri = 0, pi = 0;
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+          const int b = q >> 1, a = q & 1;
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], acc[a][b], 0, 0, 0);
+          if (have_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            // reads: one after each of the first NR MFMAs ... (A fragments first: every MFMA of the next step needs one)
+            if (q < NR) {
+              if (q < 2) af[q] = *(const h8*)(sA + q * 2048);
+              else wf[q - 2] = *(const h8*)(sW + (q - 2) * 1024);
+            }
+            // ... DMA: one after every third / fourth MFMA
+            if ((q + 1) % (NM / 5) == 0 && (q + 1) / (NM / 5) - 1 < 5) {
+              const int i = (q + 1) / (NM / 5) - 1;
+              if (!(g1 && i == 4)) piece(off, g1, live, s4, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
-      saved = d2;
-      gt++;
-      sl = sl + 2 >= 5 ? sl - 3 : sl + 2;
+      if (have_next) {
+        gt++;
+        sl = sl == 4 ? 0 : sl + 1;
+      }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {  // nk is even
+      step(kt, afA, wfA, afB, wfB, kt > 0, true);
+      step(kt + 1, afB, wfB, afA, wfA, true, true);
     }
+    step(nk, afA, wfA, afB, wfB, true, false);
   };
   using I8 = std::integral_constant<int, 8>;
   using I10 = std::integral_constant<int, 10>;
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
+  using I20 = std::integral_constant<int, 20>;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
 
   // ---- accumulator-layout helpers: lane (rsel, g) of fragment row a holds columns cbase + b*4 + r ------------------
   const int cbase = wn * 160 + g * 40;
-  // add a per-column fp32 vector (bias)
-  auto add_cols = [&](f4 (&v)[2][10], const float* vec) {
+  auto load_cols = [&](const float* vec, f4 (&bv)[10]) {
 #pragma unroll
-    for (int b = 0; b < 10; b++) {
-      const f4 bv = *(const f4*)(vec + cbase + b * 4);
-#pragma unroll
-      for (int a = 0; a < 2; a++) v[a][b] += bv;
-    }
+    for (int b = 0; b < 10; b++) bv[b] = *(const f4*)(vec + cbase + b * 4);
   };
   // fp16 rows (residual sources): 40 consecutive columns = five 16-B loads per fragment row
-  auto load_rows = [&](const half_t* src, int ld, f4 (&v)[2][10], bool add) {
+  auto load_rows_raw = [&](const half_t* src, int ld, h8 (&raw)[2][5]) {
 #pragma unroll
     for (int a = 0; a < 2; a++) {
-      const int m = min(m0 + wm * 32 + a * 16 + rsel, p.M - 1);
-      const half_t* rp = src + (long long)m * ld + cbase;
+      const half_t* rp = src + (long long)(m0 + wm * 32 + a * 16 + rsel) * ld + cbase;
 #pragma unroll
-      for (int q = 0; q < 5; q++) {
-        const h8 hv = *(const h8*)(rp + q * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float f = (float)hv[j];
-          if (add) v[a][2 * q + (j >> 2)][j & 3] += f; else v[a][2 * q + (j >> 2)][j & 3] = f;
-        }
-      }
+      for (int q = 0; q < 5; q++) raw[a][q] = *(const h8*)(rp + q * 8);
     }
   };
-  // write fp16(f(v)) into the A tile (swizzled A-operand layout): global 16-B chunk index = wn*20 + g*5 + q
+  // write fp16((v - sub) * mul) into the A tile (swizzled A-operand layout): global 16-B chunk index = wn*20 + g*5 + q
   auto store_a_tile = [&](const f4 (&v)[2][10], float mul0, float sub0, float mul1, float sub1) {
 #pragma unroll
     for (int a = 0; a < 2; a++) {
@@ -234,10 +299,11 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
     }
   };
   // LayerNorm of the residual stream into the A tile: (x - mean) / (sigma + eps), population sigma, no affine
-  // (helpers/utils.mojo:2052-2061 via :1845-1885; App.A D8).  Two-pass, exact.
+  // (helpers/utils.mojo:2052-2061 via :1845-1885; App.A D8).  Each column wave computes the exact two-pass mean / M2
+  // of its 160 columns; the two are merged after ONE exchange (Chan et al.).
   float* scr = (float*)(smem + SCR_OFF);
   auto layernorm_to_a = [&](const f4 (&v)[2][10]) {
-    float s[2], mean[2], rs[2];
+    float mw[2], m2w[2];
 #pragma unroll
     for (int a = 0; a < 2; a++) {
       float t = 0.f;
@@ -245,28 +311,26 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
       for (int b = 0; b < 10; b++) t += (v[a][b][0] + v[a][b][1]) + (v[a][b][2] + v[a][b][3]);
       t += __shfl_xor(t, 16);
       t += __shfl_xor(t, 32);
-      s[a] = t;
-      if (g == 0) scr[(wm * 32 + a * 16 + rsel) * 2 + wn] = t;
-    }
-    lds_barrier();  // also: every wave is past its last read of the old A tile
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const f2 pr = *(const f2*)(scr + (wm * 32 + a * 16 + rsel) * 2);
-      mean[a] = (pr[0] + pr[1]) * (1.f / C);
-      float t = 0.f;
+      mw[a] = t * (1.f / 160.f);
+      float u = 0.f;
 #pragma unroll
       for (int b = 0; b < 10; b++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const float d = v[a][b][r] - mean[a]; t += d * d; }
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);
-      if (g == 0) scr[128 + (wm * 32 + a * 16 + rsel) * 2 + wn] = t;
+        for (int r = 0; r < 4; r++) { const float d = v[a][b][r] - mw[a]; u += d * d; }
+      u += __shfl_xor(u, 16);
+      u += __shfl_xor(u, 32);
+      m2w[a] = u;
+      if (g == 0) *(f2*)(scr + ((wm * 32 + a * 16 + rsel) * 2 + wn) * 2) = f2{mw[a], u};
     }
-    lds_barrier();
+    lds_barrier();  // also: every wave is past its last read of the old A tile
+    float mean[2], rs[2];
 #pragma unroll
     for (int a = 0; a < 2; a++) {
-      const f2 pr = *(const f2*)(scr + 128 + (wm * 32 + a * 16 + rsel) * 2);
-      rs[a] = 1.f / (sqrtf((pr[0] + pr[1]) * (1.f / C)) + p.eps);
+      const f2 o = *(const f2*)(scr + ((wm * 32 + a * 16 + rsel) * 2 + (wn ^ 1)) * 2);
+      const float dm = mw[a] - o[0];
+      mean[a] = 0.5f * (mw[a] + o[0]);
+      const float m2 = m2w[a] + o[1] + dm * dm * 80.f;
+      rs[a] = 1.f / (sqrtf(m2 * (1.f / C)) + p.eps);
     }
     store_a_tile(v, rs[0], mean[0], rs[1], mean[1]);
   };
@@ -274,87 +338,109 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   // =================================================================================================================
   f4 T[2][10];    // residual stream (fp32)
   f4 acc[2][10];  // stage accumulators
-  // ---- prologue: residual 1 -> T ; ao tile -> A tile ; first three half-tiles of the weight stream --------------------
-  load_rows(p.tok, p.ld_tok, T, false);
+  f4 bv[10];      // per-column epilogue vector of the current stage (prefetched under the stage's GEMM)
+  h8 raw[2][5];   // residual rows in flight (tok, later x)
+  // ---- prologue: ao tile -> A tile ; residual 1 and the first bias in flight ; four weight tiles ahead ---------------
   {
     const rsrc_t ra = make_rsrc(p.ao);
 #pragma unroll
     for (int i = 0; i < 10; i++) {  // 40 pieces of [8 rows][128 B]: piece j = k-tile j/8, rows (j%8)*8 ..
       const int j = wave + 4 * i, kt = j >> 3, row = (j & 7) * 8 + lrow;
-      const int m = min(m0 + row, p.M - 1);
-      blds16(ra, (unsigned)(m * p.ld_ao + cch * 8) * 2, kt * 128, smem + A_OFF + kt * A_KT + (j & 7) * 1024);
+      blds16(ra, (unsigned)((m0 + row) * p.ld_ao + cch * 8) * 2, kt * 128, smem + A_OFF + kt * A_KT + (j & 7) * 1024);
     }
   }
+  load_rows_raw(p.tok, p.ld_tok, raw);
+  load_cols(p.bso, bv);
   seg_begin(0);
+  CTS(1);
   // ---- tok2 = ao . Wso^T + b + tok ------------------------------------------------------------------------------------
-  gemm(I10{}, S0{}, acc, A_OFF, 5);
-  add_cols(acc, p.bso);
+  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10);
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 10; b++) T[a][b] += acc[a][b];
-  layernorm_to_a(T);
-  // ---- q = LN(tok2) . Wq^T  (scaled by softmax scale * log2 e) -----------------------------------------------------------
-  gemm(I10{}, S0{}, acc, A_OFF, 5);
-  wait_vm<0>();   // the dead tail of segment 0 has landed: the ring region is free for the context keys
-  lds_barrier();  // every wave is done reading LN(tok2)
-  store_a_tile(acc, p.qscale, 0.f, p.qscale, 0.f);
-
-  // ---- cross attention over the sample's T context keys (helpers/attention.mojo:105-115) ------------------------------
-  // K tile: 5 k-tiles x [96 key rows][128 B] in the weight-operand layout.  LDS row b*16 + ii holds key
-  // 32*(b>>1) + 8*(ii>>2) + 4*(b&1) + (ii&3): output lane (g, r) of the key fragments 2kk and 2kk+1 then holds keys
-  // 32kk + 8g + 0..7 - exactly the A fragment of P.V k-step kk.
-  {
-    const rsrc_t rk = make_rsrc(p.Kc + bsmp * p.sK);
+    for (int q = 0; q < 5; q++)
 #pragma unroll
-    for (int i = 0; i < 15; i++) {  // 60 pieces: k-tile j/12, rows (j%12)*8 ..
-      const int j = wave + 4 * i, kt = j / 12, rho = (j - kt * 12) * 8 + lrow;
-      const int b = rho >> 4, ii = rho & 15;
-      const int kidx = 32 * (b >> 1) + 8 * (ii >> 2) + 4 * (b & 1) + (ii & 3);
-      const unsigned v = kidx < p.T ? (unsigned)(kidx * p.ldk + cch * 8) * 2 : PAD_OFF;
-      blds16(rk, v, kt * 128, smem + RING_OFF + kt * 12288 + (j - kt * 12) * 1024);
+      for (int j = 0; j < 8; j++) {
+        const int b = 2 * q + (j >> 2), r = j & 3;
+        T[a][b][r] = (float)raw[a][q][j] + (acc[a][b][r] + bv[b][r]);
+      }
+  CTS(2);
+  layernorm_to_a(T);
+  CTS(3);
+  // ---- q = LN(tok2) . Wq^T  (scaled by softmax scale * log2 e) -----------------------------------------------------------
+  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10);
+  CTS(4);
+  wait_vm<0>();   // the dead tail of segment 0 has landed: the ring region is free for the context keys / values
+  lds_barrier();  // every wave is done reading LN(tok2) and the last weight tile
+  // ---- cross attention over the sample's T context keys (helpers/attention.mojo:105-115) ------------------------------
+  // Ring region: K tile 5 k-tiles x [80 key rows][128 B] (weight-operand layout) | V^T keys 0..63 [320 rows][128 B] |
+  // V^T keys 64..79 [320 rows][32 B].  K row b*16 + ii holds key 32*(b>>1) + 8*(ii>>2) + 4*(b&1) + (ii&3) for b < 4
+  // (output lane (g, r) of the key fragments 2kk, 2kk+1 then holds keys 32kk + 8g + 0..7: the A fragment of P.V k-step
+  // kk) and key 64 + ii for b = 4 (k-step 2 pairs lane group g with keys 64 + 4g .. + 3).
+  constexpr int KT_B = 80 * 128, V0_OFF = 5 * KT_B, V1_OFF = V0_OFF + 320 * 128;
+  static_assert(V1_OFF + 320 * 32 <= NSLOT * SLOT, "context tiles must fit in the ring region");
+  {
+    const rsrc_t rk = make_rsrc(p.Kc + bsmp * p.sK), rv = make_rsrc(p.Vt + bsmp * p.sVt);
+    const int nch = (p.T + 7) >> 3;
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+      const int j = wave + 4 * i;  // 100 pieces of 1 KiB
+      if (j < 50) {                // K: k-tile j/10, rows (j%10)*8 ..
+        const int kt = j / 10, rho = (j - kt * 10) * 8 + lrow, b = rho >> 4, ii = rho & 15;
+        const int kidx = b < 4 ? 32 * (b >> 1) + 8 * (ii >> 2) + 4 * (b & 1) + (ii & 3) : 64 + ii;
+        blds16(rk, kidx < p.T ? (unsigned)(kidx * p.ldk + cch * 8) * 2 : PAD_OFF, kt * 128,
+               smem + RING_OFF + kt * KT_B + (j - kt * 10) * 1024);
+      } else if (j < 90) {         // V^T keys 0..63: rows (j-50)*8 ..
+        const int row = (j - 50) * 8 + lrow;
+        blds16(rv, cch < nch ? (unsigned)(row * p.ldvt + cch * 8) * 2 : PAD_OFF, 0, smem + RING_OFF + V0_OFF + (j - 50) * 1024);
+      } else {                     // V^T keys 64..79: 32 rows x 32 B per piece
+        const int row = (j - 90) * 32 + (lane >> 1), ch = 8 + (lane & 1);
+        blds16(rv, ch < nch ? (unsigned)(row * p.ldvt + ch * 8) * 2 : PAD_OFF, 0, smem + RING_OFF + V1_OFF + (j - 90) * 1024);
+      }
     }
   }
-  wait_vm<0>();
-  lds_barrier();  // q tile and K tile visible
-  // per wave: rows wm*32.., heads 4*wn .. 4*wn+3 ; P (fp16 A fragments) and 1/rowsum kept for all four heads
-  h8 pf[4][2][3];
-  float rinv[4][2];
+  store_a_tile(acc, p.qscale, 0.f, p.qscale, 0.f);  // q -> A tile while the context tiles fly
+  load_cols(p.bco, bv);
+  wait_vm<10>();  // the context tiles have landed (the 10 bias loads are younger)
+  lds_barrier();  // q tile and context tiles visible
+  // per wave: rows wm*32.., heads 4*wn .. 4*wn+3
 #pragma unroll
   for (int hh = 0; hh < 4; hh++) {
     const int h = wn * 4 + hh, c0 = h * 5;  // first 16-B chunk of the head's 40 columns
-    f4 sc[2][6];
+    f4 sc[2][5];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int b = 0; b < 6; b++) sc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 5; b++) sc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < 2; st++) {
       // k-step 0: chunks c0 .. c0+3 ; k-step 1: chunk c0+4 in lane group 0, zeros in the key operand elsewhere
       const int cg = st == 0 ? c0 + g : c0 + 4;
       const int ktile = cg >> 3, cpos = cg & 7;
-      h8 qa[2], kb[6];
+      h8 qa[2], kb[5];
 #pragma unroll
       for (int a = 0; a < 2; a++) qa[a] = *(const h8*)(smem + A_OFF + ktile * A_KT + a_rd + a * 2048 + ((cpos ^ key) << 4));
 #pragma unroll
-      for (int b = 0; b < 6; b++) {
-        kb[b] = *(const h8*)(smem + RING_OFF + ktile * 12288 + (b * 16 + rsel) * 128 + ((cpos ^ key) << 4));
+      for (int b = 0; b < 5; b++) {
+        kb[b] = *(const h8*)(smem + RING_OFF + ktile * KT_B + (b * 16 + rsel) * 128 + ((cpos ^ key) << 4));
         if (st == 1 && g != 0) kb[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
       }
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 6; b++) sc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb[b], qa[a], sc[a][b], 0, 0, 0);
+        for (int b = 0; b < 5; b++) sc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb[b], qa[a], sc[a][b], 0, 0, 0);
     }
-    // softmax over the keys of each query row: 24 in-lane scores x 4 lane groups (softmax with max subtraction, App.A D6)
+    // softmax over the keys of each query row: 20 in-lane scores x 4 lane groups (max subtraction, App.A D6)
+    h8 pf[2][3];
+    float rinv[2];
 #pragma unroll
     for (int a = 0; a < 2; a++) {
       float mx = -1.0e30f;
 #pragma unroll
-      for (int b = 0; b < 6; b++)
+      for (int b = 0; b < 5; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int kidx = 32 * (b >> 1) + 8 * g + 4 * (b & 1) + r;
+          const int kidx = b < 4 ? 32 * (b >> 1) + 8 * g + 4 * (b & 1) + r : 64 + 4 * g + r;
           if (kidx >= p.T) sc[a][b][r] = -1.0e30f;
           mx = fmaxf(mx, sc[a][b][r]);
         }
@@ -366,35 +452,18 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
         h8 o;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const half_t ph = (half_t)__builtin_amdgcn_exp2f(sc[a][2 * kk + (j >> 2)][j & 3] - mx);
+          half_t ph = (half_t)0.f;
+          if (kk < 2 || j < 4) ph = (half_t)__builtin_amdgcn_exp2f(sc[a][kk < 2 ? 2 * kk + (j >> 2) : 4][j & 3] - mx);
           o[j] = ph;
           sum += (float)ph;  // the normaliser sums the SAME rounded probabilities the MFMA multiplies
         }
-        pf[hh][a][kk] = o;
+        pf[a][kk] = o;
       }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      rinv[hh][a] = 1.f / sum;
+      rinv[a] = 1.f / sum;
     }
-  }
-  lds_barrier();  // every wave is done with the K tile (and with q)
-  // V^T tile: 2 k-tiles x [320 channel rows][128 B] (keys 0..63 | 64..127; chunks past the T keys are zero)
-  {
-    const rsrc_t rv = make_rsrc(p.Vt + bsmp * p.sVt);
-    const int nch = (p.T + 7) >> 3;
-#pragma unroll
-    for (int i = 0; i < 20; i++) {  // 80 pieces: k-tile j/40, rows (j%40)*8 ..
-      const int j = wave + 4 * i, kt = j / 40, row = (j - kt * 40) * 8 + lrow;
-      const int ch = kt * 8 + cch;
-      const unsigned v = ch < nch ? (unsigned)(row * p.ldvt + ch * 8) * 2 : PAD_OFF;
-      blds16(rv, v, 0, smem + RING_OFF + kt * 40960 + (j - kt * 40) * 1024);
-    }
-  }
-  wait_vm<0>();
-  lds_barrier();
-#pragma unroll
-  for (int hh = 0; hh < 4; hh++) {
-    const int h = wn * 4 + hh;
+    // O_h = P . V_h : channel rows h*40 + b*16 + rsel of the V^T tiles (rows past the head's 40 give discarded outputs)
     f4 oc[2][3];
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -404,16 +473,22 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
     for (int kk = 0; kk < 3; kk++) {
       h8 vb[3];
 #pragma unroll
-      for (int b = 0; b < 3; b++) {  // channel rows h*40 + b*16 + rsel (rows past the head's 40 produce discarded outputs)
-        const int row = h * 40 + b * 16 + rsel;
-        vb[b] = *(const h8*)(smem + RING_OFF + (kk >> 1) * 40960 + row * 128 + ((((kk & 1) * 4 + g) ^ (row & 7)) << 4));
+      for (int b = 0; b < 3; b++) {
+        const int row = min(h * 40 + b * 16 + rsel, C - 1);
+        if (kk < 2) vb[b] = *(const h8*)(smem + RING_OFF + V0_OFF + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+        else {
+          const h4 lo = *(const h4*)(smem + RING_OFF + V1_OFF + row * 32 + g * 8);
+          vb[b] = h8{lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
+        }
       }
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 3; b++) oc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[b], pf[hh][a][kk], oc[a][b], 0, 0, 0);
+        for (int b = 0; b < 3; b++) oc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[b], pf[a][kk], oc[a][b], 0, 0, 0);
     }
-    // attention output (merged heads) -> A tile: lane (g, r) of fragment b holds channel h*40 + b*16 + 4g + r
+    // The head's output overwrites the head's q columns in the A tile.  Columns h*40 .. h*40+39 of rows wm*32 .. +31 are
+    // read (as q) by THIS wave only - heads 4wn .. 4wn+3 belong to the column wave, the rows to the row wave - and its
+    // QK^T for this head is done, so no barrier is needed.  lane (g, r) of fragment b holds channel h*40 + b*16 + 4g + r.
 #pragma unroll
     for (int a = 0; a < 2; a++) {
       const int row = wm * 32 + a * 16 + rsel;
@@ -424,22 +499,23 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
           const int col = h * 40 + d;
           h4 o;
 #pragma unroll
-          for (int r = 0; r < 4; r++) o[r] = (half_t)(oc[a][b][r] * rinv[hh][a]);
+          for (int r = 0; r < 4; r++) o[r] = (half_t)(oc[a][b][r] * rinv[a]);
           *(h4*)(smem + A_OFF + (col >> 6) * A_KT + row * 128 + ((((col >> 3) & 7) ^ key) << 4) + (col & 7) * 2) = o;
         }
       }
     }
   }
   lds_barrier();  // attention output complete in the A tile ; the ring region is free again
+  CTS(5);
   seg_begin(1);
   // ---- tok3 = attn . Wco^T + b + tok2 -------------------------------------------------------------------------------
-  gemm(I10{}, S1{}, acc, A_OFF, 5);
-  add_cols(acc, p.bco);
+  gemm(I10{}, I1{}, Yes{}, I0{}, acc, A_OFF, 10);
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 10; b++) T[a][b] += acc[a][b];
+    for (int b = 0; b < 10; b++) T[a][b] += acc[a][b] + bv[b];
   layernorm_to_a(T);
+  CTS(6);
   // ---- GEGLU feed-forward: ten chunks of 128 hidden units; the second GEMM accumulates over the chunks ------------------
   f4 acc2[2][10];
 #pragma unroll
@@ -447,61 +523,64 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
 #pragma unroll
     for (int b = 0; b < 10; b++) acc2[a][b] = f4{0.f, 0.f, 0.f, 0.f};
   for (int jc = 0; jc < 10; jc++) {
-    gemm(I8{}, S1{}, acc, A_OFF, 5);  // (a, g) interleaved: 256 columns
+    if (jc == 5) CTS(10);
+    f4 b1v[8];  // this chunk's (a, g) bias pairs: in flight under the chunk's first GEMM
     {
-      const float* bv = p.b1 + jc * 256 + wn * 128 + g * 32;
+      const float* bp = p.b1 + jc * 256 + wn * 128 + g * 32;
 #pragma unroll
-      for (int a = 0; a < 2; a++) {
-        const int row = wm * 32 + a * 16 + rsel;
+      for (int b = 0; b < 8; b++) b1v[b] = *(const f4*)(bp + b * 4);
+    }
+    gemm(I8{}, I1{}, Yes{}, I8{}, acc, A_OFF, 10);  // (a, g) interleaved: 256 columns
+    if (jc == 5) CTS(11);
 #pragma unroll
-        for (int q = 0; q < 2; q++) {  // 16 activations per lane and fragment row = two 16-B chunks
-          h8 o;
+    for (int a = 0; a < 2; a++) {
+      const int row = wm * 32 + a * 16 + rsel;
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int b = q * 4 + (j >> 1), r = (j & 1) * 2;
-            const f4 bb = *(const f4*)(bv + b * 4);
-            o[j] = (half_t)((acc[a][b][r] + bb[r]) * gelu_tanh_c(acc[a][b][r + 1] + bb[r + 1]));
-          }
-          *(h8*)(smem + ACT_OFF + wn * A_KT + row * 128 + (((g * 2 + q) ^ key) << 4)) = o;
+      for (int q = 0; q < 2; q++) {  // 16 activations per lane and fragment row = two 16-B chunks
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int b = q * 4 + (j >> 1), r = (j & 1) * 2;
+          o[j] = (half_t)((acc[a][b][r] + b1v[b][r]) * gelu_tanh_c(acc[a][b][r + 1] + b1v[b][r + 1]));
         }
+        *(h8*)(smem + ACT_OFF + wn * A_KT + row * 128 + (((g * 2 + q) ^ key) << 4)) = o;
       }
     }
-    // the tile barrier that opens the next GEMM makes the activations visible (and 5 barriers separate this chunk's
-    // reads from the next chunk's writes)
-    f4 t2[2][10];
-    gemm(I10{}, S1{}, t2, ACT_OFF, 2);
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 10; b++) acc2[a][b] += t2[a][b];
+    // the tile barrier that opens the next GEMM makes the activations visible (and the 10 tile barriers of the next
+    // chunk's first GEMM separate this chunk's reads from the next chunk's writes)
+    if (jc == 5) CTS(12);
+    gemm(I10{}, I1{}, No{}, I0{}, acc2, ACT_OFF, 4);
+    if (jc == 5) CTS(13);
   }
-  add_cols(acc2, p.b2);
+  CTS(7);
+  load_cols(p.b2, bv);
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 10; b++) T[a][b] += acc2[a][b];
+    for (int b = 0; b < 10; b++) T[a][b] += acc2[a][b] + bv[b];
   // tok4 -> A tile (every wave passed the last GEGLU-1 tile long ago: the A tile is free)
   store_a_tile(T, 1.f, 0.f, 1.f, 0.f);
   // ---- out = tok4 . Wout^T + b + x --------------------------------------------------------------------------------
-  gemm(I10{}, S1{}, acc, A_OFF, 5);
-  add_cols(acc, p.bout);
-  load_rows(p.x, p.ld_x, acc, true);
+  load_cols(p.bout, bv);
+  load_rows_raw(p.x, p.ld_x, raw);
+  gemm(I10{}, I1{}, Yes{}, I20{}, acc, A_OFF, 10);
+  CTS(8);
   float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 groups of 10 channels
 #pragma unroll
   for (int a = 0; a < 2; a++) {
-    const int m = m0 + wm * 32 + a * 16 + rsel;
-    half_t* op = p.out + (long long)m * p.ld_out + cbase;
+    half_t* op = p.out + (long long)(m0 + wm * 32 + a * 16 + rsel) * p.ld_out + cbase;
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       h8 o;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        o[j] = (half_t)acc[a][2 * q + (j >> 2)][j & 3];
+        const int b = 2 * q + (j >> 2), r = j & 3;
+        o[j] = (half_t)((float)raw[a][q][j] + (acc[a][b][r] + bv[b][r]));
         const float f = (float)o[j];
         const int grp = (q * 8 + j) / 10;
         gs1[grp] += f; gs2[grp] += f * f;
       }
-      if (m < p.M) *(h8*)(op + q * 8) = o;
+      *(h8*)(op + q * 8) = o;
     }
   }
   if (p.gn_part) {
@@ -519,18 +598,40 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
     }
   }
   wait_vm<0>();  // the dead tail DMAs have landed before the workgroup's LDS is released
+  CTS(9);
+  CTS(15);
 }
 
+#ifdef TSD_CHAIN_TS
+extern "C" int tsd_debug_chain_ts(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // ---- host side ----------------------------------------------------------------------------------------------------
+size_t attn_tail_stream_bytes() { return (size_t)STREAM_BYTES; }
+
 bool attn_tail_supported(int C_, int d, int heads, int T, int64_t M, int S) {
   static const int on = getenv("TSD_CHAIN") ? atoi(getenv("TSD_CHAIN")) : 1;
-  return on && C_ == 320 && d == 40 && heads == 8 && T >= 1 && T <= 96 && S % 64 == 0 && M % 64 == 0 && M < (1 << 24);
+  return on && C_ == 320 && d == 40 && heads == 8 && T >= 1 && T <= 80 && S % 64 == 0 && M % 64 == 0 && M < (1 << 24);
+}
+
+// pack the six weight matrices of one attention block (fp16, reference-packed [N][K] with the GEGLU rows interleaved)
+int launch_attn_tail_pack(tsd_ctx* ctx, const half_t* Wso, int ld_so, const half_t* Wq, int ld_q, const half_t* Wco, int ld_co,
+                          const half_t* W1, int ld_1, const half_t* W2, int ld_2, const half_t* Wout, int ld_out, half_t* dst) {
+  if (ld_so < 320 || ld_q < 320 || ld_co < 320 || ld_1 < 320 || ld_2 < 1280 || ld_out < 320)
+    TSD_FAIL(TSD_E_SHAPE, "attention tail: unexpected weight pitches");
+  if (!ctx->launch()) return TSD_OK;
+  const int n = STREAM_BYTES / 16;
+  hipLaunchKernelGGL(k_attn_tail_pack, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, PackSrc{Wso, ld_so}, PackSrc{Wq, ld_q},
+                     PackSrc{Wco, ld_co}, PackSrc{W1, ld_1}, PackSrc{W2, ld_2}, PackSrc{Wout, ld_out}, dst);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
 }
 
 int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   if (!attn_tail_supported(a.C, a.d, a.heads, a.T, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention tail: unsupported shape");
-  if (a.ldw_so != 320 || a.ldw_q != 320 || a.ldw_co != 320 || a.ldw_1 != 320 || a.ldw_2 != 1280 || a.ldw_out != 320)
-    TSD_FAIL(TSD_E_SHAPE, "attention tail: unexpected weight pitches");
+  if (!a.wstream) TSD_FAIL(TSD_E_ARG, "attention tail: weights were not packed");
   if (a.ld_ao % 8 || a.ld_tok % 8 || a.ld_x % 8 || a.ld_out % 8 || a.ldk % 8 || a.ldvt % 8)
     TSD_FAIL(TSD_E_SHAPE, "attention tail: misaligned pitches");
   if (!ctx->launch()) return TSD_OK;
@@ -538,17 +639,13 @@ int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   TailK k;
   k.ao = a.ao; k.tok = a.tok; k.x = a.x; k.out = a.out;
   k.ld_ao = a.ld_ao; k.ld_tok = a.ld_tok; k.ld_x = a.ld_x; k.ld_out = a.ld_out;
-  k.Wso = a.Wso; k.Wq = a.Wq; k.Wco = a.Wco; k.W1 = a.W1; k.W2 = a.W2; k.Wout = a.Wout;
+  k.wstream = a.wstream;
   k.bso = a.bso; k.bco = a.bco; k.b1 = a.b1; k.b2 = a.b2; k.bout = a.bout;
   k.Kc = a.Kc; k.ldk = a.ldk; k.sK = a.sK; k.Vt = a.Vt; k.ldvt = a.ldvt; k.sVt = a.sVt;
   k.T = a.T; k.M = (int)a.M; k.S = a.S;
   k.qscale = a.scale * 1.4426950408889634f; k.eps = a.eps;
   k.gn_part = a.gn_part; k.gn_nslab = a.gn_nslab;
-  static bool attr = false;
-  if (!attr) {
-    HIP_TRY(hipFuncSetAttribute((const void*)attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr = true;
-  }
+  HIP_TRY(hipFuncSetAttribute((const void*)attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   hipLaunchKernelGGL(attn_tail_kernel, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;

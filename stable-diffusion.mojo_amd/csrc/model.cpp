@@ -4,6 +4,20 @@
 
 #include "model.h"
 
+bool attn_tail_weights_ok(const AttnW& w) {
+  const int C = w.C;
+  const bool plain = !w.ln[1].w && !w.ln[1].b && !w.ln[2].w && !w.ln[2].b && !w.gelu_erf;
+  return plain && C == 320 && w.n_head == 8 && w.n_embed == 40 && w.sa_out.b && w.ca_out.b && w.geglu1.b && w.geglu2.b &&
+         w.conv_out.b && !w.ca_q.b && w.sa_out.Kpad == C && w.ca_q.Kpad == C && w.ca_out.Kpad == C && w.geglu1.Kpad == C &&
+         w.geglu2.Kpad == 4 * C && w.conv_out.Ipad == C && w.conv_out.k == 1;
+}
+
+// parameters changed: derived buffers are stale until the next model_check_ready()
+static void model_invalidate_derived(tsd_model* m) {
+  m->ready = false;
+  for (auto& a : m->unet.attn) a.tail_stream = nullptr;
+}
+
 static size_t packed_bytes(const ParamSpec& p) {
   if (!p.used) return 0;
   switch (p.kind) {
@@ -58,6 +72,7 @@ extern "C" int tsd_model_destroy(tsd_model* m) {
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
   if (m->blob) hipFree(m->blob);
+  if (m->derived) hipFree(m->derived);
   delete m;
   return TSD_OK;
 }
@@ -94,7 +109,7 @@ extern "C" int tsd_model_set_param(tsd_model* m, int index, const float* data, i
   HIP_TRY(hipMemcpyAsync(ctx->staging, data, (size_t)numel * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   TSD_TRY(pack_param(m, index, (const float*)ctx->staging));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  m->ready = false;
+  model_invalidate_derived(m);
   return TSD_OK;
 }
 
@@ -116,7 +131,7 @@ extern "C" int tsd_model_init_random(tsd_model* m, uint64_t seed) {
     TSD_TRY(pack_param(m, (int)i, tmp));
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  m->ready = false;
+  model_invalidate_derived(m);
   return TSD_OK;
 }
 
@@ -130,8 +145,38 @@ extern "C" int tsd_model_packed_blob(tsd_model* m, void** device_ptr, size_t* by
 extern "C" int tsd_model_mark_loaded(tsd_model* m) {
   if (!m) TSD_FAIL(TSD_E_ARG, "NULL model");
   std::fill(m->loaded.begin(), m->loaded.end(), 1);
-  m->ready = false;
+  model_invalidate_derived(m);
   return TSD_OK;
+}
+
+// derived device buffers (not part of the broadcast blob: every rank rebuilds them from the packed weights)
+static int model_build_derived(tsd_model* m) {
+  if (!is_diffusion_kind(m->kind)) return TSD_OK;
+  tsd_ctx* ctx = m->ctx;
+  std::vector<AttnW*> el;
+  for (auto& a : m->unet.attn) if (a.C && attn_tail_weights_ok(a)) el.push_back(&a);
+  if (el.empty()) return TSD_OK;
+  const size_t each = (attn_tail_stream_bytes() + 255) & ~size_t(255), need = each * el.size();
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (m->derived_bytes < need) {
+    if (m->derived) HIP_TRY(hipFree(m->derived));
+    m->derived = nullptr; m->derived_bytes = 0;
+    hipError_t e = hipMalloc((void**)&m->derived, need);
+    if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "derived weights: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    m->derived_bytes = need;
+  }
+  const bool was_planning = ctx->arena.planning;
+  ctx->arena.planning = false;
+  int r = TSD_OK;
+  for (size_t i = 0; i < el.size() && r == TSD_OK; i++) {
+    AttnW& a = *el[i];
+    half_t* dst = (half_t*)(m->derived + i * each);
+    r = launch_attn_tail_pack(ctx, a.sa_out.w, a.sa_out.Kpad, a.ca_q.w, a.ca_q.Kpad, a.ca_out.w, a.ca_out.Kpad, a.geglu1.w,
+                              a.geglu1.Kpad, a.geglu2.w, a.geglu2.Kpad, a.conv_out.w, a.conv_out.Ipad, dst);
+    if (r == TSD_OK) a.tail_stream = dst;
+  }
+  ctx->arena.planning = was_planning;
+  return r;
 }
 
 int model_check_ready(tsd_model* m) {
@@ -139,6 +184,7 @@ int model_check_ready(tsd_model* m) {
   for (size_t i = 0; i < m->params.size(); i++)
     if (m->params[i].used && !m->loaded[i])
       TSD_FAIL(TSD_E_STATE, "model parameter %s was never set", m->params[i].name.c_str());
+  TSD_TRY(model_build_derived(m));
   m->ready = true;
   return TSD_OK;
 }

@@ -64,7 +64,12 @@ struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   int kv_off = 0;  // row offset of this block in the concatenated k_proj / v_proj tables
   NormAffine gn, ln[3];  // torch-norm extension (kind 6)
   bool gelu_erf = false; // kind 6: exact GELU in the GEGLU gate (torch.nn.functional.gelu)
+  // derived: the six tail matrices re-packed as the tile stream of the fused tail kernel (kernels_chain.hip); nullptr when
+  // the block is not eligible or the model's parameters changed since the last model_check_ready()
+  const half_t* tail_stream = nullptr;
 };
+// true when the fused tail kernel can run this block's weights (reference norms, tanh GELU, C = 8 x 40)
+bool attn_tail_weights_ok(const AttnW& w);
 struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;
   LinW in_proj, out_proj;
@@ -112,6 +117,8 @@ struct tsd_model {
   VaeW vae;
   ClipW clip;
   std::map<PlanKey, size_t> plans;  // workspace high-water mark per problem shape
+  char* derived = nullptr;          // derived device buffers rebuilt by model_check_ready(): fused-tail weight streams
+  size_t derived_bytes = 0;
 };
 
 int model_resolve(tsd_model* m);                      // fill unet / vae from the packed blob
