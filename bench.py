@@ -37,48 +37,74 @@ def shard_range(total, rank, world):
     return lo, hi
 
 
-def broadcast_weights(models, rank, world, local_rank):
-    """One RCCL broadcast per model of the packed weight blob from rank 0 (torch.distributed 'nccl' = RCCL)."""
+class _DevView:
+    """Zero-copy torch view of a device allocation (the packed weight blob) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_weights(models, rank, world, device, backend="nccl"):
+    """One broadcast per model of the packed weight blob from rank 0.
+
+    backend "nccl" (= RCCL over xGMI on ROCm): `dist.broadcast` runs directly ON the blob - a zero-copy torch view of the
+    library's device allocation, no staging tensor.  backend "gloo" (CPU control plane: the N > 1 code path on a one-GPU
+    box, and the CPU tests, where `device` is "cpu" and the "blob" is host memory): the bytes go through a host tensor.
+    Any failure raises - with more than one rank the caller must NOT fall back to per-rank initialisation silently."""
     import torch
     import torch.distributed as dist
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    if os.environ.get("TSD_BENCH_FAIL_BCAST") == "1":
+        raise RuntimeError("weight broadcast failure injected by TSD_BENCH_FAIL_BCAST=1")
     t0 = time.time()
     nbytes = 0
     for m in models:
         ptr, n = m.packed_blob()
-        buf = torch.empty(n, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        m.ctx.synchronize()
-        if rank == 0:
-            assert hip.hipMemcpy(buf.data_ptr(), ptr, n, 3) == 0  # hipMemcpyDeviceToDevice
-        torch.cuda.synchronize()
-        dist.broadcast(buf, 0)
-        torch.cuda.synchronize()
+        if device == "cpu":  # host "blob" (tests): a writable view of the caller's buffer
+            buf = torch.frombuffer((ctypes.c_uint8 * n).from_address(ptr), dtype=torch.uint8)
+            dist.broadcast(buf, 0)
+        elif backend == "nccl":
+            m.ctx.synchronize()
+            buf = torch.as_tensor(_DevView(ptr, n), device=device)
+            assert buf.data_ptr() == ptr, "torch copied the blob instead of aliasing it"
+            dist.broadcast(buf, 0)
+            torch.cuda.synchronize()
+        else:  # gloo: device blob -> pinned host tensor -> gloo broadcast -> device blob
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            m.ctx.synchronize()
+            host = torch.empty(n, dtype=torch.uint8)
+            if rank == 0:
+                assert hip.hipMemcpy(host.data_ptr(), ptr, n, 2) == 0  # hipMemcpyDeviceToHost
+            dist.broadcast(host, 0)
+            if rank != 0:
+                assert hip.hipMemcpy(ptr, host.data_ptr(), n, 1) == 0  # hipMemcpyHostToDevice
         if rank != 0:
-            assert hip.hipMemcpy(ptr, buf.data_ptr(), n, 3) == 0
             m.mark_loaded()
-        del buf
         nbytes += n
     return time.time() - t0, nbytes
 
 
 def pmc_traffic_per_gemm_launch():
-    """HBM bytes per gemm_kernel launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes over this same command, scripts/gpu_pmc_bench.sh -> profiles/r01_pmc_hbm_traffic.txt), with the
-    gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads -> x2).  None when the
-    profile is absent: bench.py itself never runs a profiler."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.txt")
-    try:
-        fetch = write = launches = 0.0
-        for line in open(path).read().splitlines()[1:]:
-            parts = line.split()
-            if "gemm_kernel" not in line or len(parts) < 4:
-                continue
-            n, f, w = float(parts[-3]), float(parts[-2]), float(parts[-1])  # dispatches, KiB/dispatch, KiB/dispatch
-            fetch += n * f; write += n * w; launches += n
-        return None if launches == 0 else int((2.0 * fetch + write) * 1024 / launches)
-    except OSError:
-        return None
+    """(HBM bytes per gemm_kernel launch, source file) from the newest committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes over this same command, scripts/gpu_pmc_bench.sh -> profiles/rNN_pmc_hbm_traffic.txt),
+    with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads -> x2).
+    (None, None) when no profile is committed: bench.py itself never runs a profiler, so the figure is NOT measured by
+    this run - `traffic_source` in the JSON line says which file it came from."""
+    for name in ("r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            fetch = write = launches = 0.0
+            for line in open(path).read().splitlines()[1:]:
+                parts = line.split()
+                if "gemm_kernel" not in line or len(parts) < 4:
+                    continue
+                n, f, w = float(parts[-3]), float(parts[-2]), float(parts[-1])  # dispatches, KiB/dispatch, KiB/dispatch
+                fetch += n * f; write += n * w; launches += n
+            if launches:
+                return int((2.0 * fetch + write) * 1024 / launches), "profiles/" + name
+        except OSError:
+            continue
+    return None, None
 
 
 def cpu_baseline(L, T):
@@ -109,13 +135,19 @@ def main():
     ap.add_argument("--tokens", type=int, default=77)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the VAE-decode timing used for images/s")
-    ap.add_argument("--cfg", action="store_true",
-                    help="also time the loop with classifier-free guidance (UNet batch 2B per step) as an extra field")
-    ap.add_argument("--img2img", action="store_true",
-                    help="also time the VAE encoder and report BASELINE configs[3] (encoder + 30 steps + decoder) as an extra field")
-    ap.add_argument("--sd15", action="store_true",
-                    help="also time BASELINE configs[4]: the full-size (860 M parameter) UNet at batch 4, as an extra field")
+    # the other BASELINE configs ride along as extra fields (a few seconds in total); --no-extras / --no-<name> skip them
+    ap.add_argument("--no-cfg", action="store_true", help="skip the classifier-free-guidance loop (UNet batch 2B per step)")
+    ap.add_argument("--no-img2img", action="store_true",
+                    help="skip BASELINE configs[3] (VAE encoder + 30 UNet steps + VAE decoder)")
+    ap.add_argument("--no-sd15", action="store_true", help="skip BASELINE configs[4] (full-size 860 M parameter UNet, batch 4)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: same as --no-cfg --no-img2img --no-sd15")
+    ap.add_argument("--cfg", action="store_true", help=argparse.SUPPRESS)      # accepted for compatibility: now on by default
+    ap.add_argument("--img2img", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--sd15", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.cfg = not (args.no_cfg or args.no_extras)
+    args.img2img = not (args.no_img2img or args.no_extras or args.no_decode)
+    args.sd15 = not (args.no_sd15 or args.no_extras)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,17 +184,11 @@ def main():
     bcast_s, bcast_bytes, bcast_how = 0.0, 0, "none (single GPU)"
     if use_dist:
         models = [unet.model] + ([dec.model] if dec is not None else [])
-        try:
-            if backend != "nccl":
-                raise RuntimeError("control-plane backend is not RCCL")
-            bcast_s, bcast_bytes = broadcast_weights(models, rank, world, dev_index)
-            bcast_how = "rccl broadcast of the packed blobs from rank 0"
-        except Exception as e:  # the timed path does not depend on it: the device RNG gives every rank the same weights
-            print(f"rank {rank}: weight broadcast failed ({e!r}); initialising from the shared seed instead", file=sys.stderr)
-            if rank != 0:
-                for m in models:
-                    m.init_random(SEED)
-            bcast_how = "fallback: every rank regenerated the weights from the shared seed (broadcast failed)"
+        # a failed broadcast is FATAL: a multi-GPU run that silently re-initialised every rank from the seed would hide
+        # exactly the failure the run exists to detect
+        bcast_s, bcast_bytes = broadcast_weights(models, rank, world, f"cuda:{dev_index}", backend)
+        bcast_how = ("rccl broadcast of the packed blobs from rank 0 (in place, zero-copy view of the blob)" if backend == "nccl"
+                     else f"{backend} broadcast of the packed blobs from rank 0 through host memory")
 
     # synthetic inputs: global batch of world*B independent prompts, this rank's contiguous shard
     lo, hi = shard_range(world * B, rank, world)
@@ -230,25 +256,40 @@ def main():
             S = side * side
             attn_gf += cnt * (2 * 2 * 8 * S * S * hd + 2 * 2 * 8 * S * T * hd) / 1e9
             side //= 2
-        gemm_gf = total_gf - attn_gf
-        achieved = (gemm_gf * B / 1e3) / (gemm_ms / 1e3) if gemm_ms > 0 else 0.0  # TFLOP/s
+        # the fused attention-tail kernel (kernels_chain.hip) does the six row-local GEMMs of the 64x64-level attention blocks
+        # (32 C^2 flop per token row) and their cross-attention core (4 T C per row) itself: that work is taken OFF the
+        # gemm_kernel's account and reported under the tail kernel's own roofline entry below
+        chain_recs = [r for r in recs if r[0] == "attn_tail_chain"]
+        chain_lin_gf = sum(r[1] * 32.0 * r[2] * r[2] for r in chain_recs) / P / 1e9
+        chain_att_gf = sum(r[1] * 4.0 * T * r[2] for r in chain_recs) / P / 1e9
+        gemm_gf_step = (total_gf - attn_gf) * B - chain_lin_gf
+        achieved = (gemm_gf_step / 1e3) / (gemm_ms / 1e3) if gemm_ms > 0 else 0.0  # TFLOP/s
+        traffic, traffic_src = pmc_traffic_per_gemm_launch()
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<...> (dense + conv3x3 implicit GEMM)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": pmc_traffic_per_gemm_launch(),
+                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else f"{traffic_src} (separate rocprofv3 --pmc passes of an earlier "
+                                      "build; NOT measured by this run)",
                     "launches_per_step": gemm_launches, "avg_launch_us": round(1e3 * gemm_ms / max(1, gemm_launches), 2),
-                    "algorithmic_gflop_per_step": round(gemm_gf * B, 1),
+                    "algorithmic_gflop_per_step": round(gemm_gf_step, 1),
                     "event_overhead_us_per_launch_removed": round(1e3 * ev_overhead_ms, 3),
                     "per_class_ms_per_step": {k: round(v[0], 4) for k, v in per_step.items()},
                     "per_class_launches_per_step": {k: v[1] for k, v in per_step.items()}}
         # secondary kernels against their own rooflines (same pass, same per-launch correction): attention on the fp16
         # MFMA peak (algorithmic 4*B*H*Sq*Sk*d per launch), the norms on HBM (algorithmic bytes = read once + write once)
         sec = {}
-        for cls in ("flash_attention", "groupnorm", "layernorm"):
+        for cls in ("flash_attention", "attn_tail_chain", "groupnorm", "layernorm"):
             ms_c, n_c = per_step[cls]
             if ms_c <= 0:
                 continue
             rs = [r for r in recs if r[0] == cls]
-            if cls == "flash_attention":
+            if cls == "attn_tail_chain":
+                tf = (chain_lin_gf + chain_att_gf) / 1e3 / (ms_c / 1e3)
+                sec[cls] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / PEAK_FP16_TFLOPS, 4), "ms_per_step": round(ms_c, 4), "launches_per_step": n_c,
+                            "replaces": "9 launches per block: out_proj+res, LN, q_proj, cross-attention, out_proj+res, LN, "
+                                        "GEGLU-1, GEGLU-2+res, conv_out+res"}
+            elif cls == "flash_attention":
                 tf = sum(4.0 * r[1] * r[2] * r[3] * r[4] for r in rs) / P / 1e12 / (ms_c / 1e3)
                 sec[cls] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tf / PEAK_FP16_TFLOPS, 4), "ms_per_step": round(ms_c, 4)}
@@ -307,7 +348,7 @@ def main():
             s5.close()
             big.model.close()
         # ---- BASELINE configs[3] (img2img): VAE encoder on B x (3,512,512) + strength 0.6 of the schedule + decoder ----
-        enc_ms = None
+        enc_ms = enc_dev_ms = None
         if args.img2img and dec is not None:
             enc = tsd.Encoder(seed=SEED, ctx=ctx)
             img = tsd.rng.uniform(SEED, 7, B * 3 * 64 * L * L, 1.0).reshape(B, 3, 8 * L, 8 * L)
@@ -316,6 +357,11 @@ def main():
             t0 = time.time()
             enc.forward(img, nz)  # boundary call: host buffers in and out (PCIe-inclusive)
             enc_ms = 1e3 * (time.time() - t0)
+            ctx.profile_begin()   # device time of the same call: sum of its kernel launches (hipEvent pairs)
+            enc.forward(img, nz)
+            enc_recs = ctx.profile_records()
+            ctx.profile_end()
+            enc_dev_ms = sum(r[5] for r in enc_recs)
             enc.model.close()
         images_per_s = (world * B) / ((n_sched * ms_per_step + (dec_ms or 0.0)) / 1e3)
         cpu = None
@@ -341,8 +387,20 @@ def main():
             "images_per_s_end_to_end": round(images_per_s, 4), "decode_ms": None if dec_ms is None else round(dec_ms, 3),
             "cfg_ms_per_step": None if cfg_ms is None else round(cfg_ms, 4),
             "img2img_config4": None if enc_ms is None else {
-                "encode_ms_host_boundary": round(enc_ms, 3), "steps": int(n_sched * 0.6),
-                "images_per_s": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
+                "workload": f"VAE encoder on {B} x (3,{8 * L},{8 * L}) + {int(n_sched * 0.6)} UNet steps + VAE decoder (BASELINE configs[3])",
+                "encode_ms_host_boundary": round(enc_ms, 3), "encode_ms_device": round(enc_dev_ms, 3), "steps": int(n_sched * 0.6),
+                "images_per_s": round(world * B / ((enc_dev_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4),
+                "images_per_s_host_boundary_encode": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
+            # the VAE halves of the hot path against the fp16 MFMA peak (algorithmic GFLOP per image: SURVEY.md Appendix B)
+            "vae_roofline": {
+                "decoder": None if dec_ms is None else {
+                    "bound": "mfma", "ms": round(dec_ms, 3), "algorithmic_gflop": round(tsd.flop_count("decoder", L) * B, 1),
+                    "achieved": round(tsd.flop_count("decoder", L) * B / dec_ms, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tsd.flop_count("decoder", L) * B / dec_ms / PEAK_FP16_TFLOPS, 4)},
+                "encoder": None if enc_dev_ms is None else {
+                    "bound": "mfma", "ms": round(enc_dev_ms, 3), "algorithmic_gflop": round(tsd.flop_count("encoder", 8 * L) * B, 1),
+                    "achieved": round(tsd.flop_count("encoder", 8 * L) * B / enc_dev_ms, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tsd.flop_count("encoder", 8 * L) * B / enc_dev_ms / PEAK_FP16_TFLOPS, 4)}},
             "sd15_config5": sd15,
             "event_ms_per_step": round(ev_ms / K, 4), "output_finite": finite,
             "frac_of_fp16_mfma_peak_whole_step": round(whole_frac, 4),

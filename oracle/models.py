@@ -196,7 +196,7 @@ def diffusion(P, x, context, t320, sem=DEFAULT, trace=None):
 def vae_attention_block(P, prefix, x, sem=DEFAULT, tn=False):
     """`Attention_Block.forward` vae.mojo:17-27: GN32 -> tokens -> Self_Attention(1 head, biases on) -> + x."""
     C, H, W = x.shape
-    h = _gn(P, prefix + ".group_norm", x, 32, C, 1e-5, tn)
+    h = _gn(P, prefix + ".group_norm", x, 32, C, 1e-6 if tn else 1e-5, tn)  # trained VAE (diffusers AutoencoderKL): eps 1e-6
     tok = ops.chw_to_tokens(h)
     tok = ops.self_attention(tok, 1, P[prefix + ".attention.in_proj.weight"], P[prefix + ".attention.in_proj.bias"],
                              P[prefix + ".attention.out_proj.weight"], P[prefix + ".attention.out_proj.bias"], sem=sem)
@@ -206,10 +206,10 @@ def vae_attention_block(P, prefix, x, sem=DEFAULT, tn=False):
 def vae_res_block(P, prefix, x, cin, cout, tn=False):
     """`Res_Block.forward` vae.mojo:57-67: GN16 -> SiLU -> Conv3x3 -> GN16 -> SiLU -> Conv3x3 ; + x or + Conv1x1(x)."""
     g = 32 if tn else 16  # the trained VAE has 32 groups (extension); the reference declares 16 (vae.mojo:42-43)
-    h = _gn(P, prefix + ".group_norm1", x, g, cin, 1e-5, tn)
+    h = _gn(P, prefix + ".group_norm1", x, g, cin, 1e-6 if tn else 1e-5, tn)
     h = ops.silu(h)
     h = _conv(P, prefix + ".conv1", h, (1, 1))
-    h = _gn(P, prefix + ".group_norm2", h, g, cout, 1e-5, tn)
+    h = _gn(P, prefix + ".group_norm2", h, g, cout, 1e-6 if tn else 1e-5, tn)
     h = ops.silu(h)
     h = _conv(P, prefix + ".conv2", h, (1, 1))
     res = x if cin == cout else _conv(P, prefix + ".res_conv_layer", x, (0, 0))
@@ -232,7 +232,7 @@ def _vae_run(P, layers, x, sem, trace=None, tn=False):
         elif kind == "up":
             h = ops.upsample_nearest2x(h)
         elif kind == "gn":
-            h = _gn(P, name, h, a[0], a[1], 1e-5, tn)
+            h = _gn(P, name, h, a[0], a[1], 1e-6 if tn else 1e-5, tn)
         elif kind == "silu":
             h = ops.silu(h)
         if trace is not None:

@@ -29,7 +29,7 @@ int run_model(tsd_model* m, F&& fn) {
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (r != TSD_OK) return r;
   if (e != hipSuccess) TSD_FAIL(TSD_E_HIP, "stream synchronize failed: %s", hipGetErrorString(e));
-  return TSD_OK;
+  return ctx_check_splitk(ctx);
 }
 }  // namespace
 
@@ -207,6 +207,8 @@ extern "C" int tsd_session_set_schedule(tsd_session* s, int num_training_steps, 
     TSD_FAIL(TSD_E_ARG, "schedule: train=%d infer=%d start=%d", num_training_steps, num_inference_steps, start_step);
   s->n_train = num_training_steps; s->n_infer = num_inference_steps; s->start = start_step;
   build_schedule(s);
+  // the device noise buffer and the workspace plan were sized for the OLD schedule: a new upload() is required
+  s->uploaded = false; s->has_noise = false;
   return TSD_OK;
 }
 extern "C" int tsd_session_num_steps(tsd_session* s) { return s ? (int)s->timesteps.size() : TSD_E_ARG; }
@@ -336,6 +338,7 @@ extern "C" int tsd_session_download_latents(tsd_session* s, float* latents) {
   NOTNULL(s); NOTNULL(latents);
   HIP_TRY(hipMemcpyAsync(latents, s->latents, (size_t)s->B * 4 * s->L * s->L * 4, hipMemcpyDeviceToHost, s->ctx->stream));
   HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+  TSD_TRY(ctx_check_splitk(s->ctx));
   return TSD_OK;
 }
 
@@ -352,7 +355,7 @@ extern "C" int tsd_session_download_images(tsd_session* s, int rescale_0_255, fl
   }
   HIP_TRY(hipMemcpyAsync(images, src, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return TSD_OK;
+  return ctx_check_splitk(ctx);
 }
 
 // ---- RCCL weight broadcast over xGMI ---------------------------------------

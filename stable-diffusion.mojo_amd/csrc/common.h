@@ -52,8 +52,9 @@ struct tsd_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Arena arena;
-  int* sk_flags = nullptr;  // 4096 zeroed ints, allocated on first use: one split-K arrival flag per tile (re-armed by the
-                            // consumers) and, at [4095], a count of hand-offs that timed out
+  int* sk_flags = nullptr;  // 4096 zeroed ints, allocated on first use: one split-K arrival flag per (slice, tile) holding the
+                            // epoch of the launch that published it and, at [4095], a sticky count of hand-offs that timed out
+  unsigned sk_epoch = 0;    // split-K launches so far on this context (the flag value of the next launch; never 0)
   half_t* zeros = nullptr;  // 4 KiB: [0,2048) zeros (padded im2col taps / head dims); [2048,2176) fp16 ones
   void* staging = nullptr;  // device staging for host<->device copies
   size_t staging_cap = 0;
@@ -98,6 +99,9 @@ struct ProfScope {
 };
 
 int ctx_reserve_arena(tsd_ctx* ctx, size_t bytes);
+// call after a stream synchronize: TSD_E_STATE if any split-K hand-off of this context ever timed out (results since then
+// cannot be trusted)
+int ctx_check_splitk(tsd_ctx* ctx);
 int ctx_reserve_staging(tsd_ctx* ctx, size_t bytes);
 
 // ---- device tensor views (NHWC fp16 activations) ---------------------------------------

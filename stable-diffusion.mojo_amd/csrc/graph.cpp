@@ -92,12 +92,12 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   // GN -> SiLU (only the first cin channels are normalised/consumed: App.A D11)
   Act h = act_alloc(ctx, B, Hin, Win, cin); CHECK_ALLOC(h.p);
   const bool x_stats = !(x.p1 && cin > x.C0) && x.gn_part0 && x.gn_groups0 == w.groups && x.C0 == cin;
-  TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, 1e-5f, 1.f, 1, h.p, h.ld,
+  TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, w.eps, 1.f, 1, h.p, h.ld,
                            x_stats ? x.gn_part0 : nullptr, x.gn_nslab0, w.gn1.w ? &w.gn1 : nullptr));
   Act t1 = act_alloc_gn(ctx, B, H, W, cout, w.groups); CHECK_ALLOC(t1.p);
   TSD_TRY(g_conv3x3(ctx, h, w.conv1, 1, 1, 1, ups, tvec ? tvec + w.time_off : nullptr, tld, nullptr, 0, false, t1.p, t1.ld, &t1));
   Act h3 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(h3.p);
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, 1e-5f, 1.f, 1, h3.p, h3.ld, t1.gn_part,
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, w.eps, 1.f, 1, h3.p, h3.ld, t1.gn_part,
                            t1.gn_nslab, w.gn2.w ? &w.gn2 : nullptr));
   Act r;
   if (w.has_skip) {  // 1x1 conv on the raw input, at the INPUT resolution (commutes with nearest upsample)
@@ -294,7 +294,7 @@ int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act& out) {
   const size_t mark = ctx->arena.mark();
   half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
   const bool x_stats = x.gn_part && x.gn_groups == 32;
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-5f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr, x.gn_nslab,
+  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, w.eps, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr, x.gn_nslab,
                            w.gn.w ? &w.gn : nullptr));
   half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
   half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * S); CHECK_ALLOC(vt);
@@ -521,7 +521,7 @@ static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, 
       Act y = act_alloc(ctx, B, cur.H, cur.W, l.b); CHECK_ALLOC(y.p);
       const int silu = (i + 1 < n_layers && layers[i + 1].kind == L_SILU) ? 1 : 0;
       const bool st = cur.gn_part && cur.gn_groups == l.a && cur.C == l.b;
-      TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), l.b), B, cur.H * cur.W, l.b, l.a, 1e-5f, 1.f, silu, y.p, y.ld,
+      TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), l.b), B, cur.H * cur.W, l.b, l.a, v.gn_eps, 1.f, silu, y.p, y.ld,
                                st ? cur.gn_part : nullptr, cur.gn_nslab, v.gn[i].w ? &v.gn[i] : nullptr));
       cur = y;
       continue;

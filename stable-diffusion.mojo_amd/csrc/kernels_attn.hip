@@ -380,10 +380,10 @@ static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
   constexpr int LDS = NST * (64 * KPITCH * 16 + DBLK * 32 * 128);
   auto fn = flash_attn_kernel<D, NST>;
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;  // one bit per device
+  if (!((attr >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr = true;
+    attr |= 1ull << (ctx->device & 63);
   }
   hipLaunchKernelGGL(fn, dim3(ceil_div(Sq, 128), B * H), dim3(256), LDS, ctx->stream, k);
   HIP_TRY(hipGetLastError());

@@ -645,7 +645,11 @@ int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   k.T = a.T; k.M = (int)a.M; k.S = a.S;
   k.qscale = a.scale * 1.4426950408889634f; k.eps = a.eps;
   k.gn_part = a.gn_part; k.gn_nslab = a.gn_nslab;
-  HIP_TRY(hipFuncSetAttribute((const void*)attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  static unsigned long long attr = 0;  // one bit per device
+  if (!((attr >> (ctx->device & 63)) & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr |= 1ull << (ctx->device & 63);
+  }
   hipLaunchKernelGGL(attn_tail_kernel, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;

@@ -61,7 +61,7 @@ struct GemmK {
   int epi, tiles_n, xcd_n;
   float out_scale;
   float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
-  float* sk_ws; int* sk_flags; int splitk; int sk_cfg;  // split-K (2/4/8 slices): fp32 partial tiles + one arrival flag per (slice, tile); host: tile cfg
+  float* sk_ws; int* sk_flags; int splitk; int sk_cfg; int sk_epoch;  // split-K (2/4/8 slices): fp32 partial tiles + one arrival flag per (slice, tile); host: tile cfg
 #ifdef TSD_GEMM_TS
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
 #endif
@@ -435,15 +435,18 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[a][b]), rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the flag
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(p.sk_flags + (ks - 1) * ntile + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(p.sk_flags + (ks - 1) * ntile + tile, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
+    // Flags carry the launch's epoch (a per-context counter, never 0) and are never reset: a producer of an EARLIER launch
+    // that lands late cannot arm this launch's hand-off, and a consumer that gives up leaves nothing armed behind it.
     for (int sl = 1; sl < S; sl++) {  // consumer: fixed order slice 0 + slice 1 + ... (bitwise reproducible)
       int* flag = p.sk_flags + (sl - 1) * ntile + tile;
       if (tid == 0) {  // bounded relaxed poll (producers have the lower block ids: always resident first)
         int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(4);
-        if (spins >= (1 << 18)) atomicAdd(&p.sk_flags[4095], 1);  // timed out: tsd_debug_splitk_errors() reports it
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(4);
+        // timed out: counted in a sticky per-context word that tsd_ctx_synchronize / the session downloads turn into TSD_E_STATE
+        if (spins >= (1 << 20)) atomicAdd(&p.sk_flags[4095], 1);
       }
       __syncthreads();
       float* wsw = p.sk_ws + (((long long)(sl - 1) * ntile + tile) * NW + wave) * (FM * FN * 256);
@@ -455,7 +458,6 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
           const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, ((a * FN + b) * 64 + lane) * 16, 0, /*sc1*/ 16);
           acc[a][b] += __builtin_bit_cast(f4, v);
         }
-      if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
     }
   }
   // ---- epilogue ---------------------------------------------------------------------------
@@ -706,10 +708,10 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int LDS = NS * (BM + BN) * 128;
   auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;  // per DEVICE: the attribute is stored per device (one bit each)
+  if (!((attr_set >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
+    attr_set |= 1ull << (ctx->device & 63);
     if (getenv("TSD_DEBUG_OCC")) {
       int nb = -1;
       hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, WGM * WGN * 64, LDS);
@@ -1108,13 +1110,15 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;
-  k.splitk = splitk ? ways : 1; k.sk_cfg = sk_cfg; k.sk_ws = sk_ws; k.sk_flags = nullptr;
+  k.splitk = splitk ? ways : 1; k.sk_cfg = sk_cfg; k.sk_ws = sk_ws; k.sk_flags = nullptr; k.sk_epoch = 0;
   if (splitk) {
     if (!ctx->sk_flags) {
       HIP_TRY(hipMalloc((void**)&ctx->sk_flags, 4096 * sizeof(int)));
       HIP_TRY(hipMemsetAsync(ctx->sk_flags, 0, 4096 * sizeof(int), ctx->stream));
     }
     k.sk_flags = ctx->sk_flags;
+    if (++ctx->sk_epoch == 0) ctx->sk_epoch = 1;
+    k.sk_epoch = (int)ctx->sk_epoch;
   }
   return a.conv ? dispatch<true>(ctx, k, a.batch) : dispatch<false>(ctx, k, a.batch);
 }

@@ -319,6 +319,7 @@ int model_resolve(tsd_model* m) {
       return a;
     };
     VaeW& v = m->vae;
+    v.gn_eps = torch_norms ? 1e-6f : 1e-5f;
     v.gn.assign(n_layers, NormAffine());
     v.conv.assign(n_layers, ConvW());
     v.res.assign(n_layers, ResW());
@@ -331,6 +332,7 @@ int model_resolve(tsd_model* m) {
         ResW& r = v.res[i];
         r.cin = l.a; r.cout = l.b; r.has_skip = l.a != l.b;
         r.groups = torch_norms ? 32 : 16;  // GroupNorm(16), vae.mojo:42-43 ; the trained VAE has 32
+        r.eps = torch_norms ? 1e-6f : 1e-5f;
         r.gn1 = aff(n + ".group_norm1"); r.gn2 = aff(n + ".group_norm2");
         r.conv1 = model_conv(m, n + ".conv1");
         r.conv2 = model_conv(m, n + ".conv2");
@@ -340,6 +342,7 @@ int model_resolve(tsd_model* m) {
         v.attn[i].in_proj = model_lin(m, n + ".attention.in_proj", true);
         v.attn[i].out_proj = model_lin(m, n + ".attention.out_proj", true);
         v.attn[i].gn = aff(n + ".group_norm");
+        v.attn[i].eps = torch_norms ? 1e-6f : 1e-5f;
       } else if (l.kind == L_GN) {
         v.gn[i] = aff(n);
       }

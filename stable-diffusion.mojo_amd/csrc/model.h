@@ -56,6 +56,7 @@ struct ResW {
   bool has_skip = false;
   int time_off = 0;  // column offset into the concatenated time projection [B][6720]
   NormAffine gn1, gn2;  // torch-norm extension (kind 6): per-channel affine of the two GroupNorms (w == nullptr: reference)
+  float eps = 1e-5f;    // GroupNorm epsilon (helpers/utils.mojo:1821-1826 default); 1e-6 in a trained VAE (kinds 8, 9)
 };
 struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   int n_head = 0, n_embed = 0, C = 0, d_ctx = 768;
@@ -74,6 +75,7 @@ struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;
   LinW in_proj, out_proj;
   NormAffine gn;  // torch-norm extension (kinds 8, 9)
+  float eps = 1e-5f;
 };
 
 struct UNetW {
@@ -92,6 +94,7 @@ struct VaeW {
   std::vector<ResW> res;
   std::vector<VaeAttnW> attn;
   std::vector<NormAffine> gn;   // stand-alone GroupNorm layers (torch-norm extension)
+  float gn_eps = 1e-5f;         // their epsilon (1e-6 in a trained VAE)
 };
 
 struct ClipLayerW { LinW in_proj, out_proj, l4, l5; NormAffine ln1, ln2; };  // ClipPlayer clip.mojo:23-34 (its LayerNorms have no parameters)

@@ -67,10 +67,20 @@ extern "C" int tsd_ctx_destroy(tsd_ctx* c) {
   return TSD_OK;
 }
 
+int ctx_check_splitk(tsd_ctx* c) {
+  if (!c->sk_flags) return TSD_OK;
+  int n = 0;
+  HIP_TRY(hipMemcpy(&n, c->sk_flags + 4095, sizeof(int), hipMemcpyDeviceToHost));
+  if (n != 0)
+    TSD_FAIL(TSD_E_STATE, "%d split-K hand-off(s) timed out on this context (GPU shared or preempted?): results computed "
+             "since then are invalid; destroy and re-create the context", n);
+  return TSD_OK;
+}
+
 extern "C" int tsd_ctx_synchronize(tsd_ctx* c) {
   if (!c) TSD_FAIL(TSD_E_ARG, "tsd_ctx_synchronize: ctx is NULL");
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return TSD_OK;
+  return ctx_check_splitk(c);
 }
 
 extern "C" int tsd_ctx_timer_start(tsd_ctx* c) {

@@ -98,6 +98,23 @@ class Session:
         la, cx = f32(latents), f32(context)
         uc = f32(uncond_context) if uncond_context is not None else None
         nz = f32(noise) if noise is not None else None
+        # the C side reads exactly B*4*L*L / B*T*768 / steps*B*4*L*L floats from these pointers: check the shapes here
+        B, L, T = self.B, self.L, self.T
+        if la.shape != (B, 4, L, L):
+            raise ValueError(f"latents must have shape {(B, 4, L, L)}, got {la.shape}")
+        if cx.shape != (B, T, 768):
+            raise ValueError(f"context must have shape {(B, T, 768)}, got {cx.shape}")
+        if self.cfg and uc is None:
+            raise ValueError("a CFG session needs uncond_context")
+        if uc is not None:
+            if uc.ndim == 2:
+                uc = uc[None]
+            if uc.shape == (1, T, 768) and B > 1:  # one shared negative prompt: broadcast it like Diffusion.forward does
+                uc = np.ascontiguousarray(np.broadcast_to(uc, (B, T, 768)))
+            if uc.shape != (B, T, 768):
+                raise ValueError(f"uncond_context must have shape {(B, T, 768)} (or one shared (T, 768) row), got {uc.shape}")
+        if nz is not None and nz.shape != (self.num_steps, B, 4, L, L):
+            raise ValueError(f"noise must have shape {(self.num_steps, B, 4, L, L)}, got {nz.shape}")
         check(lib().tsd_session_upload(self.h, ptr(la), ptr(cx), ptr(uc), ptr(nz), float(cfg_scale)))
 
     def step(self, i):

@@ -408,6 +408,89 @@ def test_bench_distributed_path_single_rank(gpu_ctx):
     assert d["weight_broadcast"].startswith("rccl broadcast") and d["weight_broadcast_bytes"] > 5e8
 
 
+
+def test_encoder_512px_batch8_properties(gpu_ctx, tsd_mod):
+    """BASELINE configs[3] front end at full size: the VAE encoder on 8 x (3, 512, 512) - finite, bitwise repeatable,
+    batch-invariant (a sample encoded alone equals its row of the batch)."""
+    enc = tsd_mod.Encoder(seed=SEED)
+    B, S = 8, 512
+    img = rng.uniform(SEED, 750, B * 3 * S * S, 1.0).reshape(B, 3, S, S)
+    noise = rng.normal(SEED, 751, B * 4 * 64 * 64).reshape(B, 4, 64, 64)
+    a = enc.forward(img, noise)
+    assert a.shape == (B, 4, 64, 64) and np.isfinite(a).all() and a.std() > 1e-3
+    np.testing.assert_array_equal(enc.forward(img, noise), a)
+    np.testing.assert_array_equal(enc.forward(img[5], noise[5]), a[5])
+    enc.model.close()
+
+
+def test_img2img_config4_full_size_properties(gpu_ctx, tsd_mod, diffusion, decoder):
+    """BASELINE configs[3] end to end at full size: encoder on 8 x 512x512 images, strength 0.6 of a 50-step schedule
+    (30 UNet steps at a 64x64 latent), decoder, rescale - finite images in [0, 255], bitwise repeatable."""
+    B, L = 8, 64
+    _, ctx = _inputs(B, L, tag=760)
+    image = rng.uniform(SEED, 761, B * 3 * 512 * 512, 1.0).reshape(B, 3, 512, 512) * 127.5 + 127.5
+    enc = tsd_mod.Encoder(seed=SEED)
+    kw = dict(cfg=False, inference_steps=50, seed_val=31, L=L, input_image=image, encoder=enc, strength=0.6)
+    a = tsd_mod.generate(diffusion, decoder, ctx, **kw)
+    b = tsd_mod.generate(diffusion, decoder, ctx, **kw)
+    enc.model.close()
+    assert a.shape == (B, 3, 512, 512) and np.isfinite(a).all()
+    assert a.min() >= 0.0 and a.max() <= 255.0 and a.std() > 1.0
+    np.testing.assert_array_equal(a, b)
+
+
+def test_img2img_matches_oracle_128px(gpu_ctx, tsd_mod, diffusion, decoder, unet_params, dec_params):
+    """The img2img path against the oracle at a 16x16 latent (128 px): every level of the UNet has more than one tile
+    row, the 64x64-level attention tail runs fused (S = 256 rows per sample)."""
+    B, L, steps, strength, seed = 1, 16, 5, 0.6, 23
+    nl = B * 4 * L * L
+    _, ctx = _inputs(B, L, tag=770)
+    image = rng.uniform(SEED, 771, 3 * 128 * 128, 1.0).reshape(1, 3, 128, 128) * 127.5 + 127.5
+    enc = tsd_mod.Encoder(seed=SEED)
+    out = tsd_mod.generate(diffusion, decoder, ctx, cfg=False, inference_steps=steps, seed_val=seed, L=L,
+                           input_image=image, encoder=enc, strength=strength)
+    enc.model.close()
+    P_enc = spec.init_params("encoder", SEED, only_used=True)
+    s = sampler.DDPMSampler(1000)
+    s.set_inference_timesteps(steps)
+    s.set_strength(strength)
+    n = len(s.timesteps)
+    img = (image / 127.5 - 1.0).astype(np.float32)
+    lat = models.encoder(P_enc, img[0], rng.normal(seed, 1, nl).reshape(B, 4, L, L)[0])
+    lat = s.add_noise(lat, s.timesteps[0], rng.normal(seed, 4, nl).reshape(B, 4, L, L)[0])
+    noises = rng.normal(seed, 3, n * nl).reshape(n, B, 4, L, L)[:, 0]
+    x = sampler.denoise(unet_params, lat, ctx[0], steps, noises, timesteps=s.timesteps)
+    ref = ops.rescale_to_u8_range(models.decoder(dec_params, x))[None]
+    err = float(np.abs(out - ref).mean())
+    print(f"[parity] img2img 128px, 3 of 5 steps: mean |diff| = {err:.4f} of 255, rel_l2 = {rel_l2(out, ref):.3e}")
+    assert err < 0.5 and rel_l2(out, ref) < TOL_MODEL
+
+
+def _run_bench_two_ranks_one_gpu(extra_env, port):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSD_BENCH_DEVICE="0", TSD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+                           "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=1200)
+
+
+def test_bench_two_ranks_on_one_gpu(gpu_ctx):
+    """bench.py's N = 2 code path end to end - torch.distributed.run launch, sharded prompts, weight blob broadcast from
+    rank 0 INTO rank 1's model (gloo control plane, both ranks on this box's one GPU), barrier, MAX-reduced time, one
+    JSON line from rank 0 - and the same run with an injected broadcast failure must exit non-zero."""
+    import json
+    r = _run_bench_two_ranks_one_gpu({}, 29541)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["output_finite"] and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    assert d["weight_broadcast"].startswith("gloo broadcast") and d["weight_broadcast_bytes"] > 5e8
+    bad = _run_bench_two_ranks_one_gpu({"TSD_BENCH_FAIL_BCAST": "1"}, 29542)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
 def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
     """The 16x16 level runs split-K with an in-launch hand-off (sc1 stores -> relaxed flag -> sc1 loads): after a
     headline-size forward no consumer may have timed out waiting for its partner, and the result is reproducible."""

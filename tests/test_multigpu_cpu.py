@@ -29,12 +29,32 @@ def _worker(rank, world, port, out):
     import tsd.rng as prng
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # weight blob: rank 0 generates, everyone else starts from garbage and must end up bit-identical
+    # weight blob: rank 0 generates, everyone else starts from garbage and must end up bit-identical - through the REAL
+    # bench.broadcast_weights (the function the multi-GPU bench runs), on a host "blob" with the gloo backend
     n = 1 << 16
-    blob = torch.from_numpy(prng.uniform(1234, 4096 + 7, n, 0.05).copy()) if rank == 0 else torch.full((n,), float("nan"))
-    dist.broadcast(blob, 0)
-    ref = prng.uniform(1234, 4096 + 7, n, 0.05)
-    ok_blob = bool(np.array_equal(blob.numpy(), ref))
+    ref = prng.uniform(1234, 4096 + 7, n, 0.05).astype(np.float32)
+    blob = ref.copy() if rank == 0 else np.full(n, np.nan, dtype=np.float32)
+
+    class HostModel:  # stands in for tsd.Model: same two methods broadcast_weights uses
+        loaded = False
+
+        def packed_blob(self):
+            return blob.ctypes.data, blob.nbytes
+
+        def mark_loaded(self):
+            self.loaded = True
+
+    hm = HostModel()
+    secs, nbytes = bench.broadcast_weights([hm], rank, world, "cpu", "gloo")
+    ok_blob = bool(np.array_equal(blob, ref)) and nbytes == blob.nbytes and hm.loaded == (rank != 0)
+    # an injected failure must raise on every rank (bench.py has no silent per-rank fallback any more)
+    os.environ["TSD_BENCH_FAIL_BCAST"] = "1"
+    try:
+        bench.broadcast_weights([hm], rank, world, "cpu", "gloo")
+        ok_blob = False
+    except RuntimeError:
+        pass
+    del os.environ["TSD_BENCH_FAIL_BCAST"]
     # batch shards of a global batch of world*8 prompts
     lo, hi = bench.shard_range(world * 8, rank, world)
     ids = torch.zeros(world * 8, dtype=torch.int64)
