@@ -259,9 +259,11 @@ def main():
         # the fused attention-tail kernel (kernels_chain.hip) does the six row-local GEMMs of the 64x64-level attention blocks
         # (32 C^2 flop per token row) and their cross-attention core (4 T C per row) itself: that work is taken OFF the
         # gemm_kernel's account and reported under the tail kernel's own roofline entry below
+        # (the fused HEAD kernel of the same blocks - GroupNorm-apply, conv_in, LayerNorm, q/k/V^T projections: 8 C^2 per
+        # row - is recorded in the same class with K = 1)
         chain_recs = [r for r in recs if r[0] == "attn_tail_chain"]
-        chain_lin_gf = sum(r[1] * 32.0 * r[2] * r[2] for r in chain_recs) / P / 1e9
-        chain_att_gf = sum(r[1] * 4.0 * T * r[2] for r in chain_recs) / P / 1e9
+        chain_lin_gf = sum(r[1] * (8.0 if r[3] == 1 else 32.0) * r[2] * r[2] for r in chain_recs) / P / 1e9
+        chain_att_gf = sum(r[1] * 4.0 * T * r[2] for r in chain_recs if r[3] == 0) / P / 1e9
         gemm_gf_step = (total_gf - attn_gf) * B - chain_lin_gf
         achieved = (gemm_gf_step / 1e3) / (gemm_ms / 1e3) if gemm_ms > 0 else 0.0  # TFLOP/s
         traffic, traffic_src = pmc_traffic_per_gemm_launch()
@@ -287,8 +289,9 @@ def main():
                 tf = (chain_lin_gf + chain_att_gf) / 1e3 / (ms_c / 1e3)
                 sec[cls] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tf / PEAK_FP16_TFLOPS, 4), "ms_per_step": round(ms_c, 4), "launches_per_step": n_c,
-                            "replaces": "9 launches per block: out_proj+res, LN, q_proj, cross-attention, out_proj+res, LN, "
-                                        "GEGLU-1, GEGLU-2+res, conv_out+res"}
+                            "replaces": "14 launches per 64x64-level attention block: head kernel = GroupNorm-apply, conv_in, LN, "
+                                        "q/k projection, V^T projection; tail kernel = out_proj+res, LN, q_proj, cross-attention, "
+                                        "out_proj+res, LN, GEGLU-1, GEGLU-2+res, conv_out+res"}
             elif cls == "flash_attention":
                 tf = sum(4.0 * r[1] * r[2] * r[3] * r[4] for r in rs) / P / 1e12 / (ms_c / 1e3)
                 sec[cls] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",

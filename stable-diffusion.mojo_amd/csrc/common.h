@@ -264,6 +264,25 @@ struct AttnTailArgs {
 bool attn_tail_supported(int C, int d, int heads, int T, int64_t M, int S);
 int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a);
 size_t attn_tail_stream_bytes();
+// fused head of the same block (kernels_chain.hip): GroupNorm-apply, 1x1 conv_in (-> tok), LayerNorm, q / k projections and
+// the V^T projection in ONE kernel.  gn_stats = finished (mean, 1/(sigma+eps)) pairs of the block input, [B][32][2].
+struct AttnHeadArgs {
+  const half_t* x = nullptr; int ld_x = 0;
+  const float* gn_stats = nullptr;
+  const half_t* wstream = nullptr;  // launch_attn_head_pack() image of conv_in and in_proj
+  const float* b_in = nullptr;      // conv_in bias
+  half_t* tok = nullptr; int ld_tok = 0;
+  half_t* qk = nullptr; int ld_qk = 0;              // [M][2C]: q | k
+  half_t* vt = nullptr; int ld_vt = 0; int64_t s_vt = 0;  // [B][C][ld_vt]
+  int64_t M = 0; int S = 0; float eps = 1e-5f;
+};
+size_t attn_head_stream_bytes();
+int launch_attn_head_pack(tsd_ctx* ctx, const half_t* Wc, int ld_c, const half_t* Win, int ld_in, half_t* dst);
+int launch_attn_head(tsd_ctx* ctx, const AttnHeadArgs& a);
+// finish GroupNorm statistics from producer-emitted partials [B][nslab][groups][2] -> stats [B][groups][2] (mean, gamma/(sigma+eps))
+int launch_gn_stats(tsd_ctx* ctx, const half_t* x, int ld, int B, int HW, int C, int groups, float eps, float gamma, float* stats);
+int launch_gn_finalize(tsd_ctx* ctx, const float* partial, int nslab, int B, int HW, int C, int groups, float eps, float gamma,
+                       float* stats);
 int launch_attn_tail_pack(tsd_ctx* ctx, const half_t* Wso, int ld_so, const half_t* Wq, int ld_q, const half_t* Wco, int ld_co,
                           const half_t* W1, int ld_1, const half_t* W2, int ld_2, const half_t* Wout, int ld_out, half_t* dst);
 int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a);

@@ -122,31 +122,53 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   if (S % 4) TSD_FAIL(TSD_E_SHAPE, "attention block: H*W=%d must be a multiple of 4", S);
   const size_t mark = ctx->arena.mark();
   const float scale = 1.f / sqrtf((float)d);  // helpers/attention.mojo:57-58
-  half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
   const bool x_stats = x.gn_part && x.gn_groups == 32;
-  TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr,
-                           x.gn_nslab, w.gn.w ? &w.gn : nullptr));  // :89,:116
   half_t* tok = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok);
-  CatSrc a; a.p0 = h0; a.ld0 = C; a.C0 = C;
-  TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C, nullptr, S));  // :117
   half_t* ln = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ln);
   half_t* qk = arena_alloc<half_t>(ctx, M * 2 * C); CHECK_ALLOC(qk);
   const int Sp = round_up(S, 8);
   half_t* vt = arena_alloc<half_t>(ctx, (int64_t)B * C * Sp); CHECK_ALLOC(vt);
-  if (Sp != S) TSD_TRY(zero_async(ctx, vt, (size_t)B * C * Sp * sizeof(half_t)));  // pad keys must be finite (P = 0 there)
   half_t* ao = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(ao);
-  // ---- self attention (:122-126) ----
-  TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C, w.ln[0].w ? &w.ln[0] : nullptr));
-  a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C, nullptr, S));  // q,k
-  {  // V^T[b] = W_v . ln_b^T  -> [B][C][S]
-    GemmArgs g;
-    g.A0 = w.sa_in.w + (int64_t)2 * C * w.sa_in.Kpad; g.lda0 = w.sa_in.Kpad; g.sA = 0;
-    g.Wt = ln; g.ldw = C; g.sW = (int64_t)S * C;
-    g.M = C; g.N = S; g.K = C; g.batch = B;
-    g.C = vt; g.ldc = Sp; g.sC = (int64_t)C * Sp;
-    TSD_TRY(launch_gemm(ctx, g));
+  CatSrc a;
+  // The block's head - GroupNorm-apply, conv_in, LayerNorm, q / k / V^T projections - is local to a token row as well once
+  // the GroupNorm statistics are known (the producer's epilogue emitted them): one kernel at the 64x64 level.
+  const half_t* head_stream = w.head_stream;
+  const bool head_ok = Sp == S && x.ld % 8 == 0 && attn_tail_supported(C, d, Hh, 1, M, S) && attn_head_weights_ok(w);
+  if (head_ok && !head_stream && !pre) {  // block-level entry: no model, pack on the fly
+    half_t* hs = arena_alloc<half_t>(ctx, (int64_t)attn_head_stream_bytes() / 2); CHECK_ALLOC(hs);
+    TSD_TRY(launch_attn_head_pack(ctx, w.conv_in.w, w.conv_in.Ipad, w.sa_in.w, w.sa_in.Kpad, hs));
+    head_stream = hs;
   }
+  if (head_ok && head_stream) {
+    float* st = arena_alloc<float>(ctx, (int64_t)B * 32 * 2); CHECK_ALLOC(st);
+    if (x_stats) TSD_TRY(launch_gn_finalize(ctx, x.gn_part, x.gn_nslab, B, S, C, 32, 1e-6f, 1.f, st));  // :89
+    else TSD_TRY(launch_gn_stats(ctx, x.p, x.ld, B, S, C, 32, 1e-6f, 1.f, st));  // no producer statistics: one read of x
+    AttnHeadArgs ha;
+    ha.x = x.p; ha.ld_x = x.ld; ha.gn_stats = st; ha.wstream = head_stream; ha.b_in = w.conv_in.b;
+    ha.tok = tok; ha.ld_tok = C; ha.qk = qk; ha.ld_qk = 2 * C; ha.vt = vt; ha.ld_vt = Sp; ha.s_vt = (int64_t)C * Sp;
+    ha.M = M; ha.S = S; ha.eps = 1e-5f;
+    TSD_TRY(launch_attn_head(ctx, ha));
+  } else {
+    half_t* h0 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(h0);
+    TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr,
+                             x.gn_nslab, w.gn.w ? &w.gn : nullptr));  // :89,:116
+    a.p0 = h0; a.ld0 = C; a.C0 = C;
+    TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C, nullptr, S));  // :117
+    if (Sp != S) TSD_TRY(zero_async(ctx, vt, (size_t)B * C * Sp * sizeof(half_t)));  // pad keys must be finite (P = 0 there)
+    // ---- self attention (:122-126) ----
+    TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C, w.ln[0].w ? &w.ln[0] : nullptr));
+    a.p0 = ln; a.ld0 = C; a.C0 = C;
+    TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C, nullptr, S));  // q,k
+    {  // V^T[b] = W_v . ln_b^T  -> [B][C][S]
+      GemmArgs g;
+      g.A0 = w.sa_in.w + (int64_t)2 * C * w.sa_in.Kpad; g.lda0 = w.sa_in.Kpad; g.sA = 0;
+      g.Wt = ln; g.ldw = C; g.sW = (int64_t)S * C;
+      g.M = C; g.N = S; g.K = C; g.batch = B;
+      g.C = vt; g.ldc = Sp; g.sC = (int64_t)C * Sp;
+      TSD_TRY(launch_gemm(ctx, g));
+    }
+  }
+  a.ld0 = C; a.C0 = C;
   AttnArgs fa;
   fa.Q = qk; fa.ldq = 2 * C; fa.sQ = (int64_t)S * 2 * C;
   fa.K = qk + C; fa.ldk = 2 * C; fa.sK = (int64_t)S * 2 * C;

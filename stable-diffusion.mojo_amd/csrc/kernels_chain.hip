@@ -49,6 +49,10 @@ struct TailK {
   float qscale;                               // softmax scale * log2(e), folded into q
   float eps;
   float* gn_part; int gn_nslab;               // output GroupNorm(32) statistics [B][nslab][32][2] (nullptr: none)
+  // head kernel only (KIND_HEAD): GroupNorm statistics of x, conv_in bias, q/k and V^T outputs (tok is an OUTPUT there)
+  const float* gn_stats;                      // [B][32][2] (mean, 1 / (sigma + eps)) of the block input
+  const float* b_in;
+  half_t* tok_out; half_t* qk; int ld_qk; half_t* vt; int ld_vt; long long s_vt;
 };
 
 namespace {
@@ -67,6 +71,9 @@ constexpr int FFN_CHUNK_BYTES = 10 * TILE_G1 + 4 * TILE_FULL;     // GEGLU-1 chu
 constexpr int SEG1_TILES = 10 + 10 * 14 + 10;                     // Wco, 10 x (W1 chunk, W2 chunk), Wout
 constexpr int SEG1_BYTES = 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES + 10 * TILE_FULL;
 constexpr int STREAM_BYTES = SEG0_BYTES + SEG1_BYTES;
+constexpr int KIND_TAIL = 0, KIND_HEAD = 1;
+constexpr int HEAD_TILES = 40;                                    // conv_in (10), Wq (10), Wk (10), Wv (10)
+constexpr int HEAD_STREAM_BYTES = HEAD_TILES * TILE_FULL;
 
 __device__ __forceinline__ float gelu_tanh_c(float x) {  // helpers/utils.mojo:1914 (see kernels_gemm.hip)
   const float c2 = -2.f * 0.7978845608028654f * 1.4426950408889634f;
@@ -120,6 +127,24 @@ __global__ void k_attn_tail_pack(PackSrc so, PackSrc q, PackSrc co, PackSrc w1, 
   *(h8*)(dst + (size_t)ci * 8) = *(const h8*)(W + (size_t)n * ldw + k);
 }
 
+// head stream: conv_in, then the q / k / v row blocks of in_proj (rows 0..319 / 320..639 / 640..959), all K = 320.
+// The v tiles keep the IDENTITY row order (LDS row rho of half h = weight row h*160 + rho): that stage runs with swapped
+// MFMA operands and wants consecutive channels across a fragment's 16 lanes.
+__global__ void k_attn_head_pack(PackSrc cin, PackSrc inproj, half_t* dst) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= HEAD_STREAM_BYTES / 16) return;
+  int byte = ci * 16;
+  const int ti = byte / TILE_FULL; byte -= ti * TILE_FULL;
+  const int mat = ti / 10, t = ti - mat * 10;
+  const half_t* W = mat == 0 ? cin.w : inproj.w;
+  const int ldw = mat == 0 ? cin.ldw : inproj.ldw, row0 = mat == 0 ? 0 : (mat - 1) * 320;
+  const int half = byte / 10240, rb = byte - half * 10240;
+  const int rho = rb >> 6, pc = (rb >> 4) & 3, fn = rho >> 4, ii = rho & 15;
+  const int n = row0 + half * 160 + (mat == 3 ? rho : (ii >> 2) * 40 + fn * 4 + (ii & 3));
+  const int k = 32 * t + 8 * (pc ^ wswz(rho));
+  *(h8*)(dst + (size_t)ci * 8) = *(const h8*)(W + (size_t)n * ldw + k);
+}
+
 #ifdef TSD_CHAIN_TS
 __device__ unsigned long long g_chain_ts[1024 * 16];  // per block: s_memtime at the phase marks (experiment build only)
 #define CTS(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_chain_ts[blockIdx.x * 16 + (i)] = (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
@@ -127,7 +152,8 @@ __device__ unsigned long long g_chain_ts[1024 * 16];  // per block: s_memtime at
 #define CTS(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,6 +169,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   // byte offset / size class of tile gi of a segment (wave-uniform)
   auto tile_off = [&](int seg, int gi, bool& g1, bool& live) {
     g1 = false; live = true;
+    if (KIND == KIND_HEAD) { live = gi < HEAD_TILES; return gi * TILE_FULL; }
     if (seg == 0) { live = gi < SEG0_TILES; return gi * TILE_FULL; }
     if (gi < 10) return SEG0_BYTES + gi * TILE_FULL;
     if (gi < 150) {
@@ -154,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
     live = gi < SEG1_TILES;
     return SEG0_BYTES + 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES + (gi - 150) * TILE_FULL;
   };
-  const rsrc_t rw = make_rsrc(p.wstream, STREAM_BYTES), rdead = make_rsrc(p.wstream, 0);
+  const rsrc_t rw = make_rsrc(p.wstream, KIND == KIND_HEAD ? HEAD_STREAM_BYTES : STREAM_BYTES), rdead = make_rsrc(p.wstream, 0);
   const unsigned lane16 = lane * 16;
   // piece i (of 5 per wave) of tile gi -> ring slot: 1-KiB wave-instruction number wave + 4*i of the tile image
   auto piece = [&](int off, bool g1, bool live, int slot, int i) {
@@ -179,9 +206,12 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   // tiles the first wait is for.
   const int a_rd = (wm * 32 + rsel) * 128;
   const int w_rd = rsel * 64 + ((g ^ wswz(rsel)) << 4);
-  auto gemm = [&](auto fn_c, auto seg_c, auto zero_c, auto extra_c, f4 (&acc)[2][10], int a_base, int nk) {
+  auto gemm = [&](auto fn_c, auto seg_c, auto zero_c, auto extra_c, f4 (&acc)[2][10], int a_base, int nk, auto swap_c) {
     constexpr int FN = decltype(fn_c)::value, SEG = decltype(seg_c)::value, EXTRA = decltype(extra_c)::value;
     constexpr bool ZERO = decltype(zero_c)::value;
+    // SWAP: D = Afrag x Wfrag^T instead of Wfrag x Afrag^T - a lane then holds ONE weight row (= lane & 15 of fragment b)
+    // and FOUR consecutive token rows (4g + r of fragment a): the transposed output the V^T projection needs
+    constexpr bool SWAP = decltype(swap_c)::value;
     if (ZERO) {
 #pragma unroll
       for (int a = 0; a < 2; a++)
@@ -231,7 +261,8 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
 #pragma unroll
         for (int q = 0; q < NM; q++) {
           const int b = q >> 1, a = q & 1;
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], acc[a][b], 0, 0, 0);
+          if (SWAP) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(paf[a], pwf[b], acc[a][b], 0, 0, 0);
+          else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], acc[a][b], 0, 0, 0);
           if (have_next) {
             __builtin_amdgcn_sched_barrier(0);
             // reads: one after each of the first NR MFMAs ... (A fragments first: every MFMA of the next step needs one)
@@ -335,6 +366,98 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
     store_a_tile(v, rs[0], mean[0], rs[1], mean[1]);
   };
 
+  if constexpr (KIND == KIND_HEAD) {
+    // =============================================================================================================
+    // head of the block (diffusion.mojo:116-124): GroupNorm-apply -> conv_in (1x1) -> tok ; LayerNorm -> q, k, V^T
+    f4 T[2][10], acc[2][10], accq[2][10], bv[10];
+    h8 raw[2][5];
+    load_rows_raw(p.x, p.ld_x, raw);
+    f2 gst[4];  // (mean, 1/(sigma+eps)) of this lane's four groups of 10 channels
+#pragma unroll
+    for (int k = 0; k < 4; k++) gst[k] = *(const f2*)(p.gn_stats + ((long long)bsmp * 32 + wn * 16 + g * 4 + k) * 2);
+    load_cols(p.b_in, bv);
+    seg_begin(0);
+    // GroupNorm (32 groups, eps 1e-6, no SiLU; helpers/utils.mojo:1845-1885) of the x tile -> A tile
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const int row = wm * 32 + a * 16 + rsel;
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int grp = (q * 8 + j) / 10;
+          o[j] = (half_t)(((float)raw[a][q][j] - gst[grp][0]) * gst[grp][1]);
+        }
+        const int cg = wn * 20 + g * 5 + q;
+        *(h8*)(smem + A_OFF + (cg >> 3) * A_KT + row * 128 + (((cg & 7) ^ key) << 4)) = o;
+      }
+    }
+    CTS(1);
+    // ---- tok = GN(x) . Wc^T + b  (diffusion.mojo:117) ; the first tile barrier publishes the A tile -----------------------
+    gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      half_t* op = p.tok_out + (long long)(m0 + wm * 32 + a * 16 + rsel) * p.ld_tok + cbase;
+#pragma unroll
+      for (int b = 0; b < 10; b++) T[a][b] = acc[a][b] + bv[b];
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (half_t)T[a][2 * q + (j >> 2)][j & 3];
+        *(h8*)(op + q * 8) = o;
+      }
+    }
+    CTS(2);
+    layernorm_to_a(T);   // the LayerNorm sees the fp32 tok (the unfused graph normalises its fp16 rounding)
+    wait_vm<0>();        // stores and loads share vmcnt: drain before the counted waits of the next stage rely on its order
+    CTS(3);
+    // ---- q, k = LN(tok) . W^T  (helpers/attention.mojo:29, in_bias = False) -----------------------------------------------
+    gemm(I10{}, I0{}, Yes{}, I0{}, accq, A_OFF, 10, No{});
+    gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+    CTS(4);
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      half_t* op = p.qk + (long long)(m0 + wm * 32 + a * 16 + rsel) * p.ld_qk + cbase;
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        h8 oq, ok;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { oq[j] = (half_t)accq[a][2 * q + (j >> 2)][j & 3]; ok[j] = (half_t)acc[a][2 * q + (j >> 2)][j & 3]; }
+        *(h8*)(op + q * 8) = oq;
+        *(h8*)(op + C + q * 8) = ok;
+      }
+    }
+    wait_vm<0>();
+    CTS(5);
+    // ---- V^T = Wv . LN(tok)^T : swapped operands, lane (channel wn*160 + b*16 + rsel) holds tokens wm*32 + a*16 + 4g + r ----
+    gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, Yes{});
+    CTS(6);
+    lds_barrier();  // every wave is done reading the A tile: it becomes the [320 channels][64 tokens] staging tile
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 10; b++) {
+        const int c = wn * 160 + b * 16 + rsel;
+        const int tkn = wm * 32 + a * 16 + 4 * g;  // first of this lane's four tokens
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = (half_t)acc[a][b][r];
+        *(h4*)(smem + A_OFF + c * 128 + (((tkn >> 3) ^ (c & 7)) << 4) + (tkn & 7) * 2) = o;
+      }
+    lds_barrier();
+    {
+      half_t* vb = p.vt + bsmp * p.s_vt + (m0 - bsmp * p.S);
+#pragma unroll
+      for (int i = 0; i < 10; i++) {  // 2560 16-B chunks: channel row t>>3, 8 tokens each: 128 B contiguous per row
+        const int t = tid + 256 * i, c = t >> 3, part = t & 7;
+        const h8 v = *(const h8*)(smem + A_OFF + c * 128 + ((part ^ (c & 7)) << 4));
+        *(h8*)(vb + (long long)c * p.ld_vt + part * 8) = v;
+      }
+    }
+    CTS(7); CTS(8);
+  } else {
   // =================================================================================================================
   f4 T[2][10];    // residual stream (fp32)
   f4 acc[2][10];  // stage accumulators
@@ -354,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   seg_begin(0);
   CTS(1);
   // ---- tok2 = ao . Wso^T + b + tok ------------------------------------------------------------------------------------
-  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10);
+  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -368,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   layernorm_to_a(T);
   CTS(3);
   // ---- q = LN(tok2) . Wq^T  (scaled by softmax scale * log2 e) -----------------------------------------------------------
-  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10);
+  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
   CTS(4);
   wait_vm<0>();   // the dead tail of segment 0 has landed: the ring region is free for the context keys / values
   lds_barrier();  // every wave is done reading LN(tok2) and the last weight tile
@@ -509,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   CTS(5);
   seg_begin(1);
   // ---- tok3 = attn . Wco^T + b + tok2 -------------------------------------------------------------------------------
-  gemm(I10{}, I1{}, Yes{}, I0{}, acc, A_OFF, 10);
+  gemm(I10{}, I1{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -530,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
 #pragma unroll
       for (int b = 0; b < 8; b++) b1v[b] = *(const f4*)(bp + b * 4);
     }
-    gemm(I8{}, I1{}, Yes{}, I8{}, acc, A_OFF, 10);  // (a, g) interleaved: 256 columns
+    gemm(I8{}, I1{}, Yes{}, I8{}, acc, A_OFF, 10, No{});  // (a, g) interleaved: 256 columns
     if (jc == 5) CTS(11);
 #pragma unroll
     for (int a = 0; a < 2; a++) {
@@ -549,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
     // the tile barrier that opens the next GEMM makes the activations visible (and the 10 tile barriers of the next
     // chunk's first GEMM separate this chunk's reads from the next chunk's writes)
     if (jc == 5) CTS(12);
-    gemm(I10{}, I1{}, No{}, I0{}, acc2, ACT_OFF, 4);
+    gemm(I10{}, I1{}, No{}, I0{}, acc2, ACT_OFF, 4, No{});
     if (jc == 5) CTS(13);
   }
   CTS(7);
@@ -563,7 +686,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
   // ---- out = tok4 . Wout^T + b + x --------------------------------------------------------------------------------
   load_cols(p.bout, bv);
   load_rows_raw(p.x, p.ld_x, raw);
-  gemm(I10{}, I1{}, Yes{}, I20{}, acc, A_OFF, 10);
+  gemm(I10{}, I1{}, Yes{}, I20{}, acc, A_OFF, 10, No{});
   CTS(8);
   float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 groups of 10 channels
 #pragma unroll
@@ -596,6 +719,7 @@ __global__ __launch_bounds__(256, 1) void attn_tail_kernel(const TailK p) {
 #pragma unroll
       for (int k = 0; k < 4; k++) *(f2*)(ob + k * 2) = f2{gs1[k], gs2[k]};
     }
+  }
   }
   wait_vm<0>();  // the dead tail DMAs have landed before the workgroup's LDS is released
   CTS(9);
@@ -645,12 +769,47 @@ int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   k.T = a.T; k.M = (int)a.M; k.S = a.S;
   k.qscale = a.scale * 1.4426950408889634f; k.eps = a.eps;
   k.gn_part = a.gn_part; k.gn_nslab = a.gn_nslab;
+  k.gn_stats = nullptr; k.b_in = nullptr; k.tok_out = nullptr; k.qk = nullptr; k.ld_qk = 0; k.vt = nullptr; k.ld_vt = 0; k.s_vt = 0;
   static unsigned long long attr = 0;  // one bit per device
   if (!((attr >> (ctx->device & 63)) & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_chain_kernel<KIND_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr |= 1ull << (ctx->device & 63);
   }
-  hipLaunchKernelGGL(attn_tail_kernel, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
+  hipLaunchKernelGGL(attn_chain_kernel<KIND_TAIL>, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// ---- head of the block: GroupNorm-apply -> conv_in -> tok ; LayerNorm -> q, k, V^T ------------------------------------
+size_t attn_head_stream_bytes() { return (size_t)HEAD_STREAM_BYTES; }
+
+int launch_attn_head_pack(tsd_ctx* ctx, const half_t* Wc, int ld_c, const half_t* Win, int ld_in, half_t* dst) {
+  if (ld_c < 320 || ld_in < 320) TSD_FAIL(TSD_E_SHAPE, "attention head: unexpected weight pitches");
+  if (!ctx->launch()) return TSD_OK;
+  const int n = HEAD_STREAM_BYTES / 16;
+  hipLaunchKernelGGL(k_attn_head_pack, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, PackSrc{Wc, ld_c}, PackSrc{Win, ld_in}, dst);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+int launch_attn_head(tsd_ctx* ctx, const AttnHeadArgs& a) {
+  if (!attn_tail_supported(320, 40, 8, 1, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention head: unsupported shape");
+  if (!a.wstream || !a.gn_stats) TSD_FAIL(TSD_E_ARG, "attention head: weights were not packed / statistics missing");
+  if (a.ld_x % 8 || a.ld_tok % 8 || a.ld_qk % 8 || a.ld_vt % 8 || a.ld_qk < 640 || a.ld_vt < a.S)
+    TSD_FAIL(TSD_E_SHAPE, "attention head: misaligned pitches");
+  if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_CHAIN, (int)a.M, 320, 1, 1);
+  TailK k = {};
+  k.x = a.x; k.ld_x = a.ld_x; k.tok_out = a.tok; k.ld_tok = a.ld_tok; k.qk = a.qk; k.ld_qk = a.ld_qk;
+  k.vt = a.vt; k.ld_vt = a.ld_vt; k.s_vt = a.s_vt;
+  k.wstream = a.wstream; k.b_in = a.b_in; k.gn_stats = a.gn_stats;
+  k.M = (int)a.M; k.S = a.S; k.eps = a.eps; k.T = 1;
+  static unsigned long long attr = 0;  // one bit per device
+  if (!((attr >> (ctx->device & 63)) & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_chain_kernel<KIND_HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr |= 1ull << (ctx->device & 63);
+  }
+  hipLaunchKernelGGL(attn_chain_kernel<KIND_HEAD>, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

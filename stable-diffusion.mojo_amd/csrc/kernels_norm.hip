@@ -263,6 +263,39 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   return TSD_OK;
 }
 
+int launch_gn_finalize(tsd_ctx* ctx, const float* partial, int nslab, int B, int HW, int C, int groups, float eps, float gamma,
+                       float* stats) {
+  if (!partial || nslab <= 0 || !stats || C % groups) TSD_FAIL(TSD_E_ARG, "gn_finalize: bad argument");
+  if (!ctx->launch()) return TSD_OK;
+  GnK k = {};
+  k.C = C; k.HW = HW; k.G = groups; k.cpg = C / groups; k.nslab = nslab;
+  k.partial = const_cast<float*>(partial); k.stats = stats; k.eps = eps; k.gamma = gamma; k.torch_rstd = 0;
+  ProfScope prof(ctx, KC_GROUPNORM, B * groups, nslab, 0, 1);
+  hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
+// statistics only (no apply pass): partial sums over pixel slabs, then the finalize above -> stats [B][groups][2]
+int launch_gn_stats(tsd_ctx* ctx, const half_t* x, int ld, int B, int HW, int C, int groups, float eps, float gamma, float* stats) {
+  if (C % 8 || C % groups || C > 256 * 8 * GN_MAX_CPT || ld % 8) TSD_FAIL(TSD_E_SHAPE, "gn_stats: C=%d groups=%d unsupported", C, groups);
+  GnK k = {};
+  k.x0 = x; k.ld0 = ld; k.C0 = C; k.C = C; k.HW = HW; k.G = groups; k.cpg = C / groups;
+  const int nch = C / 8, PL = nch <= 256 ? 256 / nch : 1;
+  k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 64));
+  k.nslab = ceil_div(HW, k.slab_pixels);
+  k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
+  if (!k.partial) TSD_FAIL(TSD_E_ALLOC, "gn_stats: workspace exhausted");
+  k.stats = stats; k.eps = eps; k.gamma = gamma;
+  if (!ctx->launch()) return TSD_OK;
+  ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
+  hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
 // ---- LayerNorm over the last dim of (rows, C): one wave per row, data held in registers ----
 constexpr int LN_MAX_CH = 4;  // C <= 2048
 struct LnAff { const float* w; const float* b; int torch_rstd; };

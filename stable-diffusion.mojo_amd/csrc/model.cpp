@@ -12,10 +12,16 @@ bool attn_tail_weights_ok(const AttnW& w) {
          w.geglu2.Kpad == 4 * C && w.conv_out.Ipad == C && w.conv_out.k == 1;
 }
 
+bool attn_head_weights_ok(const AttnW& w) {
+  const int C = w.C;
+  return C == 320 && w.n_head == 8 && w.n_embed == 40 && !w.gn.w && !w.gn.b && !w.ln[0].w && !w.ln[0].b && w.conv_in.b &&
+         w.conv_in.k == 1 && w.conv_in.Ipad == C && w.conv_in.Opad == C && !w.sa_in.b && w.sa_in.Kpad == C && w.sa_in.N == 3 * C;
+}
+
 // parameters changed: derived buffers are stale until the next model_check_ready()
 static void model_invalidate_derived(tsd_model* m) {
   m->ready = false;
-  for (auto& a : m->unet.attn) a.tail_stream = nullptr;
+  for (auto& a : m->unet.attn) { a.tail_stream = nullptr; a.head_stream = nullptr; }
 }
 
 static size_t packed_bytes(const ParamSpec& p) {
@@ -154,9 +160,10 @@ static int model_build_derived(tsd_model* m) {
   if (!is_diffusion_kind(m->kind)) return TSD_OK;
   tsd_ctx* ctx = m->ctx;
   std::vector<AttnW*> el;
-  for (auto& a : m->unet.attn) if (a.C && attn_tail_weights_ok(a)) el.push_back(&a);
+  for (auto& a : m->unet.attn) if (a.C && (attn_tail_weights_ok(a) || attn_head_weights_ok(a))) el.push_back(&a);
   if (el.empty()) return TSD_OK;
-  const size_t each = (attn_tail_stream_bytes() + 255) & ~size_t(255), need = each * el.size();
+  const size_t tail_b = (attn_tail_stream_bytes() + 255) & ~size_t(255), head_b = (attn_head_stream_bytes() + 255) & ~size_t(255);
+  const size_t each = tail_b + head_b, need = each * el.size();
   HIP_TRY(hipSetDevice(ctx->device));
   if (m->derived_bytes < need) {
     if (m->derived) HIP_TRY(hipFree(m->derived));
@@ -171,9 +178,16 @@ static int model_build_derived(tsd_model* m) {
   for (size_t i = 0; i < el.size() && r == TSD_OK; i++) {
     AttnW& a = *el[i];
     half_t* dst = (half_t*)(m->derived + i * each);
-    r = launch_attn_tail_pack(ctx, a.sa_out.w, a.sa_out.Kpad, a.ca_q.w, a.ca_q.Kpad, a.ca_out.w, a.ca_out.Kpad, a.geglu1.w,
-                              a.geglu1.Kpad, a.geglu2.w, a.geglu2.Kpad, a.conv_out.w, a.conv_out.Ipad, dst);
-    if (r == TSD_OK) a.tail_stream = dst;
+    if (attn_tail_weights_ok(a)) {
+      r = launch_attn_tail_pack(ctx, a.sa_out.w, a.sa_out.Kpad, a.ca_q.w, a.ca_q.Kpad, a.ca_out.w, a.ca_out.Kpad, a.geglu1.w,
+                                a.geglu1.Kpad, a.geglu2.w, a.geglu2.Kpad, a.conv_out.w, a.conv_out.Ipad, dst);
+      if (r == TSD_OK) a.tail_stream = dst;
+    }
+    if (r == TSD_OK && attn_head_weights_ok(a)) {
+      half_t* hd = (half_t*)(m->derived + i * each + tail_b);
+      r = launch_attn_head_pack(ctx, a.conv_in.w, a.conv_in.Ipad, a.sa_in.w, a.sa_in.Kpad, hd);
+      if (r == TSD_OK) a.head_stream = hd;
+    }
   }
   ctx->arena.planning = was_planning;
   return r;

@@ -68,9 +68,11 @@ struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   // derived: the six tail matrices re-packed as the tile stream of the fused tail kernel (kernels_chain.hip); nullptr when
   // the block is not eligible or the model's parameters changed since the last model_check_ready()
   const half_t* tail_stream = nullptr;
+  const half_t* head_stream = nullptr;  // same for conv_in + in_proj (fused head kernel)
 };
 // true when the fused tail kernel can run this block's weights (reference norms, tanh GELU, C = 8 x 40)
 bool attn_tail_weights_ok(const AttnW& w);
+bool attn_head_weights_ok(const AttnW& w);
 struct VaeAttnW {  // vae.mojo:9-11
   int C = 0;
   LinW in_proj, out_proj;
