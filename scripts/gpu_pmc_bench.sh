@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o r -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-decode > $R/gpurun_out/pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o r -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-decode --no-extras > $R/gpurun_out/pmc_$C.log 2>&1
   find /tmp/pmc_$C -name "*counter_collection*.csv" -exec cp {} /tmp/pmc_$C.csv \;
 done
 python3 - <<PY > $R/gpurun_out/pmc_traffic.txt

@@ -5,7 +5,7 @@ set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_sq
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_sq -o r -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-decode > $R/gpurun_out/pmc_sq.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_sq -o r -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-decode --no-extras > $R/gpurun_out/pmc_sq.log 2>&1
 find /tmp/pmc_sq -name "*counter_collection*.csv" -exec cp {} /tmp/pmc_sq.csv \;
 python3 - <<PY > $R/gpurun_out/pmc_sq.txt
 import csv, collections

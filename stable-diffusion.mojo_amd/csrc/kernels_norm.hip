@@ -12,6 +12,8 @@
 // thread, fp32 accumulation, no atomics.  The source may be the channel-concat of two tensors (UNet skip
 // connections, diffusion.mojo:253-270) so the concat is never materialised for the normalised branch.
 // LayerNorm: one group of LPR lanes per row for the UNet widths (k_layernorm_grp), one wave per row otherwise.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -233,7 +235,8 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   // stats pass: 2*GN_UNROLL pixels per thread, at most 512 slabs per sample ; apply pass: GN_UNROLL pixels per thread
   k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 64));  // <= 64 slabs: every apply block re-reduces them
   k.nslab = ceil_div(HW, k.slab_pixels);
-  k.apply_pixels = 2 * GN_UNROLL * PL;
+  static const int apply_mult = getenv("TSD_GN_APPLY_MULT") ? atoi(getenv("TSD_GN_APPLY_MULT")) : 2;
+  k.apply_pixels = apply_mult * GN_UNROLL * PL;
   // statistics already emitted by the producer's epilogue (EPI_GNSTATS, same [B][nslab][G][2] layout): no partial pass
   const bool have_stats = pre_part != nullptr && pre_nslab > 0;
   if (have_stats) { k.partial = const_cast<float*>(pre_part); k.nslab = pre_nslab; }
