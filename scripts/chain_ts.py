@@ -16,9 +16,13 @@ for _ in range(3): s.step(1)
 ctx.synchronize()
 n = 512 * 16
 buf = (C.c_ulonglong * n)()
-assert lib().tsd_debug_chain_ts(buf, n) == 0
+KIND = int(os.environ.get("KIND", 0))
+assert lib().tsd_debug_chain_ts(buf, n, KIND) == 0
 a = np.array(buf, dtype=np.uint64).reshape(512, 16).astype(np.int64)
-names = ["prologue issue", "S1 gemm (sa_out)", "LN1", "S3 gemm (q)", "cross attention", "S5 gemm + LN2", "FFN (10 chunks)", "b2+T, S9 gemm", "out store+stats"]
+if KIND == 1:
+    names = ["prologue + GN -> A", "conv_in gemm+tok store", "LN + drain", "q, k gemms", "q/k store + drain", "V^T gemm", "V^T transpose+store", "-", "final wait"]
+else:
+  names = ["prologue issue", "S1 gemm (sa_out)", "LN1", "S3 gemm (q)", "cross attention", "S5 gemm + LN2", "FFN (10 chunks)", "b2+T, S9 gemm", "out store+stats"]
 nblk = B * 64
 for lo, hi, tag in (((0, 256, "round 1 (blocks 0..255)"), (256, 512, "round 2 (blocks 256..511)")) if nblk > 256 else ((0, nblk, f"all {nblk} blocks"),)):
     blk = a[lo:hi]

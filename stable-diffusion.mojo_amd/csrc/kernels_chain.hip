@@ -146,8 +146,8 @@ __global__ void k_attn_head_pack(PackSrc cin, PackSrc inproj, half_t* dst) {
 }
 
 #ifdef TSD_CHAIN_TS
-__device__ unsigned long long g_chain_ts[1024 * 16];  // per block: s_memtime at the phase marks (experiment build only)
-#define CTS(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_chain_ts[blockIdx.x * 16 + (i)] = (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_chain_ts[2 * 1024 * 16];  // per kernel kind and block: s_memtime at the phase marks (experiment build only)
+#define CTS(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_chain_ts[(KIND * 1024 + blockIdx.x) * 16 + (i)] = (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CTS(i) do { } while (0)
 #endif
@@ -395,46 +395,57 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     }
     CTS(1);
     // ---- tok = GN(x) . Wc^T + b  (diffusion.mojo:117) ; the first tile barrier publishes the A tile -----------------------
+    // No global store happens before the last GEMM is done: stores share vmcnt with the DMA stream, and draining them
+    // (an HBM write round trip) in the middle of the kernel costs more than any stage.  tok / q / k wait in registers.
     gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+    h8 tokh[2][5];
 #pragma unroll
     for (int a = 0; a < 2; a++) {
-      half_t* op = p.tok_out + (long long)(m0 + wm * 32 + a * 16 + rsel) * p.ld_tok + cbase;
 #pragma unroll
       for (int b = 0; b < 10; b++) T[a][b] = acc[a][b] + bv[b];
 #pragma unroll
-      for (int q = 0; q < 5; q++) {
-        h8 o;
+      for (int q = 0; q < 5; q++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = (half_t)T[a][2 * q + (j >> 2)][j & 3];
-        *(h8*)(op + q * 8) = o;
-      }
+        for (int j = 0; j < 8; j++) tokh[a][q][j] = (half_t)T[a][2 * q + (j >> 2)][j & 3];
     }
     CTS(2);
     layernorm_to_a(T);   // the LayerNorm sees the fp32 tok (the unfused graph normalises its fp16 rounding)
-    wait_vm<0>();        // stores and loads share vmcnt: drain before the counted waits of the next stage rely on its order
     CTS(3);
     // ---- q, k = LN(tok) . W^T  (helpers/attention.mojo:29, in_bias = False) -----------------------------------------------
+    f4 acck[2][10];
     gemm(I10{}, I0{}, Yes{}, I0{}, accq, A_OFF, 10, No{});
-    gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+    gemm(I10{}, I0{}, Yes{}, I0{}, acck, A_OFF, 10, No{});
     CTS(4);
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-      half_t* op = p.qk + (long long)(m0 + wm * 32 + a * 16 + rsel) * p.ld_qk + cbase;
-#pragma unroll
-      for (int q = 0; q < 5; q++) {
-        h8 oq, ok;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { oq[j] = (half_t)accq[a][2 * q + (j >> 2)][j & 3]; ok[j] = (half_t)acc[a][2 * q + (j >> 2)][j & 3]; }
-        *(h8*)(op + q * 8) = oq;
-        *(h8*)(op + C + q * 8) = ok;
-      }
-    }
-    wait_vm<0>();
     CTS(5);
     // ---- V^T = Wv . LN(tok)^T : swapped operands, lane (channel wn*160 + b*16 + rsel) holds tokens wm*32 + a*16 + 4g + r ----
     gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, Yes{});
     CTS(6);
-    lds_barrier();  // every wave is done reading the A tile: it becomes the [320 channels][64 tokens] staging tile
+    lds_barrier();  // every wave is done with the A tile and the ring: both become output staging
+    // Outputs leave through LDS so that every global store instruction writes whole contiguous row segments (lane-owned
+    // 80-B row pieces stored directly are 64 scattered 16-B writes per instruction: store-issue bound).
+    //   A tile region : V^T [320 channels][64 tokens] (128-B rows, 16-B chunks XOR-swizzled by channel & 7)
+    //   ring region   : two row-major [64 rows][640 B] tiles at a 656-B pitch (conflict-free 16-B writes)
+    constexpr int RP = 656, ST0 = RING_OFF, ST1 = RING_OFF + 64 * RP;
+    static_assert(ST1 + 64 * RP <= SCR_OFF, "staging tiles must fit in the ring region");
+    // stage fragment rows: this lane's 8 columns cbase + 8q .. of fragment row a
+#define STAGE_ROWS_ACC(base, v)                                                                                         \
+  _Pragma("unroll") for (int a = 0; a < 2; a++) _Pragma("unroll") for (int q = 0; q < 5; q++) {                          \
+    h8 o_;                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 8; j++) o_[j] = (half_t)v[a][2 * q + (j >> 2)][j & 3];                         \
+    *(h8*)(smem + (base) + (wm * 32 + a * 16 + rsel) * RP + (cbase + q * 8) * 2) = o_;                                   \
+  }
+    auto flush_rows = [&](int base, half_t* dst, int ld) {  // 2560 16-B chunks, 40 per row: a wave stores 1 KiB = 1.6 full rows
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        const int t = tid + 256 * i, row = t / 40, c = t - row * 40;
+        *(h8*)(dst + (long long)(m0 + row) * ld + c * 8) = *(const h8*)(smem + base + row * RP + c * 16);
+      }
+    };
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int q = 0; q < 5; q++) *(h8*)(smem + ST0 + (wm * 32 + a * 16 + rsel) * RP + (cbase + q * 8) * 2) = tokh[a][q];
+    STAGE_ROWS_ACC(ST1, accq)
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -447,6 +458,8 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         *(h4*)(smem + A_OFF + c * 128 + (((tkn >> 3) ^ (c & 7)) << 4) + (tkn & 7) * 2) = o;
       }
     lds_barrier();
+    flush_rows(ST0, p.tok_out, p.ld_tok);
+    flush_rows(ST1, p.qk, p.ld_qk);
     {
       half_t* vb = p.vt + bsmp * p.s_vt + (m0 - bsmp * p.S);
 #pragma unroll
@@ -456,6 +469,11 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         *(h8*)(vb + (long long)c * p.ld_vt + part * 8) = v;
       }
     }
+    lds_barrier();  // staging tile 0 has been read by everyone
+    STAGE_ROWS_ACC(ST0, acck)
+#undef STAGE_ROWS_ACC
+    lds_barrier();
+    flush_rows(ST0, p.qk + C, p.ld_qk);
     CTS(7); CTS(8);
   } else {
   // =================================================================================================================
@@ -689,9 +707,11 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   gemm(I10{}, I1{}, Yes{}, I20{}, acc, A_OFF, 10, No{});
   CTS(8);
   float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 groups of 10 channels
+  lds_barrier();  // every wave is done with the A tile: it (and the idle activation tile behind it) stages the output rows
+  constexpr int RP = 656;  // row pitch of the row-major staging tile: conflict-free 16-B writes, whole-row global stores
+  static_assert(A_OFF + 64 * RP <= RING_OFF, "output staging must stay clear of the ring (dead DMAs may still land there)");
 #pragma unroll
   for (int a = 0; a < 2; a++) {
-    half_t* op = p.out + (long long)(m0 + wm * 32 + a * 16 + rsel) * p.ld_out + cbase;
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       h8 o;
@@ -703,8 +723,14 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         const int grp = (q * 8 + j) / 10;
         gs1[grp] += f; gs2[grp] += f * f;
       }
-      *(h8*)(op + q * 8) = o;
+      *(h8*)(smem + A_OFF + (wm * 32 + a * 16 + rsel) * RP + (cbase + q * 8) * 2) = o;
     }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int i = 0; i < 10; i++) {  // 2560 16-B chunks, 40 per row: a wave instruction stores 1 KiB of consecutive row bytes
+    const int t = tid + 256 * i, row = t / 40, c = t - row * 40;
+    *(h8*)(p.out + (long long)(m0 + row) * p.ld_out + c * 8) = *(const h8*)(smem + A_OFF + row * RP + c * 16);
   }
   if (p.gn_part) {
     // GroupNorm(32) statistics of the rounded output for the consumer (one 32-row slab per wave row block)
@@ -727,8 +753,8 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
 }
 
 #ifdef TSD_CHAIN_TS
-extern "C" int tsd_debug_chain_ts(unsigned long long* out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), (size_t)n * 8) == hipSuccess ? 0 : -1;
+extern "C" int tsd_debug_chain_ts(unsigned long long* out, int n, int kind) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), (size_t)n * 8, (size_t)kind * 1024 * 16 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 
