@@ -40,6 +40,9 @@
 #ifndef TSD_GEMM_PIN
 #define TSD_GEMM_PIN 1
 #endif
+#ifndef TSD_GEMM_PIPE
+#define TSD_GEMM_PIPE 1
+#endif
 #ifndef TSD_GEMM_PIN_MAXNS
 #define TSD_GEMM_PIN_MAXNS 4
 #endif
@@ -323,6 +326,82 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     TS_MARK(1);
     // the K loop starts on a 256-byte boundary (padding = s_nop, executed once): +0.45 % on the step, measured
     asm volatile(".p2align " TSD_STR(TSD_GEMM_LOOP_ALIGN));
+    // PIPE (one 4-wave block per CU, NS >= 3: nobody else on the SIMD hides LDS latency): software pipeline over the
+    // K-tiles with two fragment register sets - the 2*(FM+FN) fragment reads of tile kt are issued one at a time between
+    // the MFMAs of tile kt-1 instead of as a burst right after the barrier (72 ds_read_b128 from the four waves hold the
+    // LDS, and every wave's issue, for ~300 cycles per K-tile).  Same products in the same order: results are bitwise
+    // identical to the other schedules.
+    constexpr bool PIPE = PIN && NS >= 3 && NW == 4 && (TSD_GEMM_PIPE != 0);
+    if constexpr (PIPE) {
+      h8 afA[2][FM], wfA[2][FN], afB[2][FM], wfB[2][FN];
+      auto step = [&](int kt, h8 (&naf)[2][FM], h8 (&nwf)[2][FN], const h8 (&paf)[2][FM], const h8 (&pwf)[2][FN],
+                      bool have_prev, bool have_next) {
+        const char *sA = smem, *sW = smem;
+        TileSrc t;
+        if (have_next) {
+          const int ahead = min(NS - 2, nk - 1 - kt);
+          if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
+          else if (NS >= 5 && ahead == 3) { if (lps_hi) wait_vmcnt<3 * LPS_HI>(); else wait_vmcnt<3 * LPS_LO>(); }
+          else if (NS >= 4 && ahead == 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
+          else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
+          else wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt-1 are done: its slot may be refilled
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          sA = smem + cur * TILE_BYTES;
+          sW = sA + BM * 128;
+          t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
+        }
+        constexpr int NP = A_PW + W_PW, NM = 2 * FM * FN, NR = 2 * (FM + FN), GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
+        auto read_one = [&](int i) {  // fragment i of tile kt: per k-half the FM A fragments, then the FN W fragments
+          const int kk = i / (FM + FN), j = i - kk * (FM + FN);
+          const int coff = ((kk * 4 + cq) ^ key) << 4;
+          if (j < FM) naf[kk][j] = *(const h8*)(sA + a_rd + j * 2048 + coff);
+          else nwf[kk][j - FM] = *(const h8*)(sW + w_rd + (j - FM) * 2048 + coff);
+        };
+        if (!have_prev) {
+#pragma unroll
+          for (int i = 0; i < NR; i++) read_one(i);
+#pragma unroll
+          for (int i = 0; i < NP; i++) stage_piece(t, nxt, i);
+        } else {
+#pragma unroll
+          for (int q = 0; q < NM; q++) {
+            const int kk = q / (FM * FN), a = (q / FN) % FM, b = q % FN;
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[kk][b], paf[kk][a], acc[a][b], 0, 0, 0);
+            if (have_next) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (q < NR) read_one(q);
+              if ((q + 1) % GAP == 0 && (q + 1) / GAP - 1 < NP) stage_piece(t, nxt, (q + 1) / GAP - 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (have_next) {
+#pragma unroll
+            for (int i = NM; i < NR; i++) read_one(i);  // thin tiles: more fragments than MFMAs
+#pragma unroll
+            for (int i = NM / GAP; i < NP; i++) stage_piece(t, nxt, i);
+          }
+        }
+        if (have_next) {
+          stage_advance();
+          cur = (cur + 1 == NS) ? 0 : cur + 1;
+          nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+      };
+      step(0, afA, wfA, afB, wfB, false, true);
+      int kt = 1;
+      for (; kt + 1 < nk; kt += 2) {
+        step(kt, afB, wfB, afA, wfA, true, true);
+        step(kt + 1, afA, wfA, afB, wfB, true, true);
+      }
+      if (kt < nk) {
+        step(kt, afB, wfB, afA, wfA, true, true);
+        step(nk, afA, wfA, afB, wfB, true, false);
+      } else {
+        step(nk, afB, wfB, afA, wfA, true, false);
+      }
+    } else
     for (int kt = 0; kt < nk; kt++) {
       // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
       const int ahead = min(NS - 2, nk - 1 - kt);
