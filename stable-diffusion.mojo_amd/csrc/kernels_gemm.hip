@@ -331,7 +331,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     // the MFMAs of tile kt-1 instead of as a burst right after the barrier (72 ds_read_b128 from the four waves hold the
     // LDS, and every wave's issue, for ~300 cycles per K-tile).  Same products in the same order: results are bitwise
     // identical to the other schedules.
-    constexpr bool PIPE = PIN && NS >= 3 && NW == 4 && (TSD_GEMM_PIPE != 0);
+    constexpr bool PIPE = PIN && (NS >= 3 || FM * FN <= 10) && NW == 4 && (TSD_GEMM_PIPE != 0);
     if constexpr (PIPE) {
       h8 afA[2][FM], wfA[2][FN], afB[2][FM], wfB[2][FN];
       auto step = [&](int kt, h8 (&naf)[2][FM], h8 (&nwf)[2][FN], const h8 (&paf)[2][FM], const h8 (&pwf)[2][FN],
