@@ -278,6 +278,10 @@ int tsd_dist_finalize(tsd_ctx* ctx);
  * 1 when workgroups map to XCDs round-robin (the precondition of the L2-local split-K hand-off). */
 int tsd_debug_splitk_errors(tsd_ctx* ctx);
 int tsd_debug_xcd_round_robin(void);
+/* A/B switch for the fused attention-block kernels of the 64x64 level (kernels_chain.hip): 0 = op-by-op graph, 1 = fused
+ * (default; TSD_CHAIN=0 in the environment has the same effect).  Returns the previous setting.  Sessions sized their
+ * workspace for the graph active at upload(): switch before creating the session. */
+int tsd_debug_set_fused_attention(int on);
 int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
                          int iters, float* ms);
 

@@ -761,8 +761,16 @@ extern "C" int tsd_debug_chain_ts(unsigned long long* out, int n, int kind) {
 // ---- host side ----------------------------------------------------------------------------------------------------
 size_t attn_tail_stream_bytes() { return (size_t)STREAM_BYTES; }
 
+static int g_chain_on = -1;  // -1: read TSD_CHAIN on first use
+// debug / A-B switch: 1 = fused head / tail kernels at the 64x64 level (default), 0 = the op-by-op graph; returns the old value
+extern "C" int tsd_debug_set_fused_attention(int on) {
+  const int old = g_chain_on < 0 ? (getenv("TSD_CHAIN") ? atoi(getenv("TSD_CHAIN")) : 1) : g_chain_on;
+  g_chain_on = on ? 1 : 0;
+  return old;
+}
 bool attn_tail_supported(int C_, int d, int heads, int T, int64_t M, int S) {
-  static const int on = getenv("TSD_CHAIN") ? atoi(getenv("TSD_CHAIN")) : 1;
+  if (g_chain_on < 0) g_chain_on = getenv("TSD_CHAIN") ? atoi(getenv("TSD_CHAIN")) : 1;
+  const int on = g_chain_on;
   return on && C_ == 320 && d == 40 && heads == 8 && T >= 1 && T <= 80 && S % 64 == 0 && M % 64 == 0 && M < (1 << 24);
 }
 

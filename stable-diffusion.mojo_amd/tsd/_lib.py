@@ -107,6 +107,7 @@ def _declare(l):
         "tsd_flop_count": ([i, i, i], C.c_double),
         "tsd_debug_splitk_errors": ([vp], i),
         "tsd_debug_xcd_round_robin": ([], i),
+        "tsd_debug_set_fused_attention": ([i], i),
         "tsd_debug_gemm_bench": ([vp, i, i, i, i, i, i, i, i, i, i, fp], i),
         "tsd_debug_attn_bench": ([vp, i, i, i, i, i, i, fp], i),
         "tsd_debug_gemm_check": ([vp, i, i, i, i, i, i, i, i, i, i, fp, fp], i),

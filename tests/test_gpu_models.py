@@ -466,6 +466,30 @@ def test_img2img_matches_oracle_128px(gpu_ctx, tsd_mod, diffusion, decoder, unet
     assert err < 0.5 and rel_l2(out, ref) < TOL_MODEL
 
 
+
+def test_fused_attention_blocks_match_unfused_graph_at_full_size(gpu_ctx, tsd_mod, diffusion):
+    """The fused head / tail kernels of the 64x64-level attention blocks (kernels_chain.hip) against the op-by-op graph they
+    replace, at the headline size (batch 8, 64x64 latent: M = 32768 rows, 512 workgroups in two rounds) - the sizes the
+    oracle is too slow for.  Both paths are within fp16 rounding of each other (the fused path keeps the residual stream in
+    fp32), the fused path is bitwise repeatable and batch-invariant."""
+    from tsd._lib import lib
+    lat, ctx = _inputs(8, 64, tag=780)
+    temb = np.stack([ops.time_embedding(t) for t in (980.0, 860.0, 700.0, 500.0, 300.0, 120.0, 20.0, 0.0)])
+    old = lib().tsd_debug_set_fused_attention(1)
+    try:
+        fused = diffusion.forward(lat, ctx, temb)
+        np.testing.assert_array_equal(diffusion.forward(lat, ctx, temb), fused)
+        np.testing.assert_array_equal(diffusion.forward(lat[3], ctx[3], temb[3]), fused[3])
+        lib().tsd_debug_set_fused_attention(0)
+        plain = diffusion.forward(lat, ctx, temb)
+    finally:
+        lib().tsd_debug_set_fused_attention(old)
+    assert np.isfinite(fused).all() and np.isfinite(plain).all()
+    err = rel_l2(fused, plain)
+    print(f"[parity] fused vs op-by-op attention blocks, B=8 L=64: rel_l2 = {err:.3e}")
+    assert err < 3e-3
+
+
 def _run_bench_two_ranks_one_gpu(extra_env, port):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
