@@ -169,11 +169,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 #pragma unroll
   for (int q = 0; q < GN_MAX_CPT; q++) {
     const int ch = m.ch0 + q * 256;
+    // group of each of the 8 channels: ONE integer division per chunk (a 32-bit division is ~40 instructions, and this
+    // prologue runs in every block for a payload of only 8 pixels per thread), then a running remainder
+    int g = ch < m.nch ? (ch * 8) / p.cpg : 0;
+    int rem = ch < m.nch ? ch * 8 - g * p.cpg : 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int g = ch < m.nch ? (ch * 8 + j) / p.cpg : 0;
       mu[q][j] = st[2 * g];
       ri[q][j] = st[2 * g + 1];
+      if (++rem == p.cpg && ch < m.nch) { rem = 0; ++g; }
     }
   }
   float sh[AFFINE ? GN_MAX_CPT : 1][8];  // AFFINE: per-channel weight folded into ri, bias kept as a shift
