@@ -157,6 +157,8 @@ def main():
     B, L, T = args.batch, args.latent, args.tokens
 
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before anything initialises HIP (see tsd/_lib.py)
+    if world > 1 or os.environ.get("TSD_BENCH_FORCE_DIST") == "1":
+        import torch  # noqa: F401  BEFORE libtsd: a process must hold ONE HIP runtime, and torch bundles its own
     import tsd
     tsd.set_strict(True)
     dist = None

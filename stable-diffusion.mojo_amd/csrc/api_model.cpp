@@ -376,10 +376,19 @@ struct Rccl {
 Rccl g_rccl;
 int rccl_load() {
   if (g_rccl.lib) return TSD_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // A process must use ONE HIP runtime: torch wheels bundle their own libamdhip64 + librccl, and an RCCL built against the
+  // other runtime fails in ncclCommInitRank ("unhandled cuda error": round-1 log, libtsd loaded /opt/rocm's runtime first
+  // and a later `import torch` mapped a second one).  So: first take an RCCL that is ALREADY mapped (RTLD_NOLOAD; it belongs
+  // to the runtime the process is using - with torch imported first libtsd itself binds to torch's libamdhip64, same
+  // SONAME), and only otherwise load the system one.  scripts/diag_rccl_coresident.py shows the three cases.
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
-    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     if (g_rccl.lib) break;
+  }
+  for (int i = 0; i < 3 && !g_rccl.lib; i++) {
+    const char* order[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    g_rccl.lib = dlopen(order[i], RTLD_NOW | RTLD_GLOBAL);
   }
   if (!g_rccl.lib) TSD_FAIL(TSD_E_RCCL, "cannot dlopen librccl: %s", dlerror());
   g_rccl.get_uid = (fn_get_uid)dlsym(g_rccl.lib, "ncclGetUniqueId");
