@@ -53,9 +53,16 @@ def test_full_size_unet_inventory(tsd_mod):
 
 
 def test_rng_twins_agree():
+    """The host mirror's counter RNG == the oracle's (the two files are written twice on purpose),
+    both pinned by known answers so the pair cannot drift together; the DEVICE generator is pinned against the host one by
+    tests/test_gpu_models.py::test_device_rng_equals_host_rng."""
     import tsd.rng as prng
     np.testing.assert_array_equal(prng.uniform(5, 77, 1000, 0.3), orng.uniform(5, 77, 1000, 0.3))
     np.testing.assert_array_equal(prng.normal(5, 78, 1000), orng.normal(5, 78, 1000))
+    kat_u = np.array([-0.17280828952789307, -0.03223922476172447, 0.08573245257139206, 0.2056889683008194], dtype=np.float32)
+    kat_n = np.array([0.04646738991141319, 0.09456849843263626, 1.1540602445602417, 0.024450836703181267], dtype=np.float32)
+    np.testing.assert_array_equal(prng.uniform(5, 77, 4, 0.3), kat_u)
+    np.testing.assert_array_equal(orng.normal(5, 78, 4), kat_n)
     u = prng.uniform(1, 2, 200000, 1.0)
     assert abs(u.mean()) < 0.01 and abs(u.std() - 1 / np.sqrt(3)) < 0.01 and u.min() >= -1 and u.max() < 1
     z = prng.normal(1, 3, 200000)
