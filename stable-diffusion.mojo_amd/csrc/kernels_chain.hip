@@ -790,8 +790,11 @@ int launch_attn_tail_pack(tsd_ctx* ctx, const half_t* Wso, int ld_so, const half
 int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   if (!attn_tail_supported(a.C, a.d, a.heads, a.T, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention tail: unsupported shape");
   if (!a.wstream) TSD_FAIL(TSD_E_ARG, "attention tail: weights were not packed");
-  if (a.ld_ao % 8 || a.ld_tok % 8 || a.ld_x % 8 || a.ld_out % 8 || a.ldk % 8 || a.ldvt % 8)
-    TSD_FAIL(TSD_E_SHAPE, "attention tail: misaligned pitches");
+  if (a.ld_ao % 8 || a.ld_tok % 8 || a.ld_x % 8 || a.ld_out % 8 || a.ldk % 8 || a.ldvt % 8 || a.ld_ao < 320 || a.ld_tok < 320 ||
+      a.ld_x < 320 || a.ld_out < 320 || a.ldk < 320 || a.ldvt < ((a.T + 7) & ~7))
+    TSD_FAIL(TSD_E_SHAPE, "attention tail: misaligned or too narrow pitches");
+  if (!a.ao || !a.tok || !a.x || !a.out || !a.Kc || !a.Vt || !a.bso || !a.bco || !a.b1 || !a.b2 || !a.bout)
+    TSD_FAIL(TSD_E_ARG, "attention tail: NULL operand");
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_CHAIN, (int)a.M, a.C, 0, 1);
   TailK k;
@@ -829,8 +832,9 @@ int launch_attn_head_pack(tsd_ctx* ctx, const half_t* Wc, int ld_c, const half_t
 int launch_attn_head(tsd_ctx* ctx, const AttnHeadArgs& a) {
   if (!attn_tail_supported(320, 40, 8, 1, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention head: unsupported shape");
   if (!a.wstream || !a.gn_stats) TSD_FAIL(TSD_E_ARG, "attention head: weights were not packed / statistics missing");
-  if (a.ld_x % 8 || a.ld_tok % 8 || a.ld_qk % 8 || a.ld_vt % 8 || a.ld_qk < 640 || a.ld_vt < a.S)
-    TSD_FAIL(TSD_E_SHAPE, "attention head: misaligned pitches");
+  if (a.ld_x % 8 || a.ld_tok % 8 || a.ld_qk % 8 || a.ld_vt % 8 || a.ld_x < 320 || a.ld_tok < 320 || a.ld_qk < 640 || a.ld_vt < a.S)
+    TSD_FAIL(TSD_E_SHAPE, "attention head: misaligned or too narrow pitches");
+  if (!a.x || !a.tok || !a.qk || !a.vt || !a.b_in) TSD_FAIL(TSD_E_ARG, "attention head: NULL operand");
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_CHAIN, (int)a.M, 320, 1, 1);
   TailK k = {};
