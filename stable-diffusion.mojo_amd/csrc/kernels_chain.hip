@@ -420,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     // ---- V^T = Wv . LN(tok)^T : swapped operands, lane (channel wn*160 + b*16 + rsel) holds tokens wm*32 + a*16 + 4g + r ----
     gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, Yes{});
     CTS(6);
+    wait_vm<0>();   // the dead tail DMAs (zero-size descriptors still WRITE zeros) have landed: the ring is really free
     lds_barrier();  // every wave is done with the A tile and the ring: both become output staging
     // Outputs leave through LDS so that every global store instruction writes whole contiguous row segments (lane-owned
     // 80-B row pieces stored directly are 64 scattered 16-B writes per instruction: store-issue bound).
