@@ -467,6 +467,34 @@ def test_img2img_matches_oracle_128px(gpu_ctx, tsd_mod, diffusion, decoder, unet
 
 
 
+
+def test_session_argument_checks(gpu_ctx, tsd_mod, diffusion):
+    """Host-side guards of the device-resident loop: wrong array shapes are rejected before the C side reads past a buffer, a
+    single shared negative prompt is broadcast over the batch, and a new schedule invalidates the previous upload."""
+    B, L = 2, 8
+    lat, ctx = _inputs(B, L, tag=790)
+    s = tsd_mod.Session(diffusion.model, None, B, L, 77, cfg=True)
+    s.set_schedule(1000, 3, 0)
+    with pytest.raises(ValueError):
+        s.upload(lat[:1], ctx, ctx, None)                       # latents for one sample only
+    with pytest.raises(ValueError):
+        s.upload(lat, ctx[:, :5], ctx, None)                    # context with 5 tokens in a 77-token session
+    with pytest.raises(ValueError):
+        s.upload(lat, ctx, None, None)                          # CFG session without a negative prompt
+    with pytest.raises(ValueError):
+        s.upload(lat, ctx, ctx, np.zeros((2, B, 4, L, L), np.float32))   # noise for 2 of the 3 steps
+    s.upload(lat, ctx, ctx[0], None)                            # one shared (77, 768) negative prompt: broadcast
+    s.step(0)
+    a = s.latents()
+    s.upload(lat, ctx, np.stack([ctx[0], ctx[0]]), None)
+    s.step(0)
+    np.testing.assert_array_equal(s.latents(), a)
+    s.set_schedule(1000, 5, 0)                                  # more steps than the uploaded noise / plan covered
+    with pytest.raises(tsd_mod.TsdError):
+        s.step(0)
+    s.close()
+
+
 def test_fused_attention_blocks_match_unfused_graph_at_full_size(gpu_ctx, tsd_mod, diffusion):
     """The fused head / tail kernels of the 64x64-level attention blocks (kernels_chain.hip) against the op-by-op graph they
     replace, at the headline size (batch 8, 64x64 latent: M = 32768 rows, 512 workgroups in two rounds) - the sizes the
