@@ -48,17 +48,15 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 #ifdef TSD_ATTN_TS
 __device__ unsigned long long g_attn_ts[4 * 65536];  // per block: memtime start/end, memrealtime start/end
 #endif
-// a*b + c as ONE unpacked v_fma_f32 (the SLP vectoriser would pair two of them into v_pk_fma_f32)
-__device__ __forceinline__ float fma1(float a, float b, float c) {
-  float r;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// Largest score (log2 units, relative to the running reference) a tile may reach before the reference is moved.
+// P = exp2(s - ref) is then at most 2^12 - far inside fp16 (65504) and harmless for the fp32 O / row-sum accumulators.
+#define TSD_ATTN_LAZY 12.0f
 
-template <int D, int NST>
+template <int D>
 // min 2 waves/SIMD: caps the budget at 256 unified registers so the MFMA results stay in VGPRs (no v_accvgpr moves
 // around the softmax / rescale VALU work).
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
+__global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const AttnK p) {
+  constexpr int NST = 2;                   // K / V^T tile buffers
   constexpr int DCH = D / 8;               // 16-B chunks per K row
   constexpr int KSTEPS = (DCH + 1) / 2;    // QK^T k-steps (16 wide)
   // LDS pitch of a K row in 16-B chunks: odd -> conflict-free ds_read_b128.  d=40: the 5 data chunks already are an odd
@@ -106,6 +104,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
       const int ch = ks * 2 + hi;
       if (ch < DCH) qf[ks] = *(const h8*)(qp + ch * 8);
       else qf[ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+      // scale * log2(e) goes into Q once (fp32 multiply, one fp16 rounding), so the MFMA result is already the exponent
+      // and the per-score v_fma_f32 of the softmax disappears
+#pragma unroll
+      for (int e = 0; e < 8; e++) qf[ks][e] = (half_t)((float)qf[ks][e] * p.c);
     }
   }
 
@@ -168,46 +170,39 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
   for (int d = 0; d < DBLK; d++)
 #pragma unroll
     for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
+  // Online softmax with a LAZY reference: the exponent s - ref comes straight out of the QK^T MFMAs (ref enters as their
+  // C operand, a 16-register block holding -ref), and ref only moves when a tile's largest exponent exceeds
+  // TSD_ATTN_LAZY - after the first tile that is rare, so a tile's VALU work is max3, exp2 and the fp16 convert only.
+  // Tile 0 always sets ref to its exact row maximum (so every row has a P >= 2^-LAZY ... 1 term and the sum cannot
+  // underflow); afterwards ref >= (running max) - LAZY, P <= 2^LAZY.
+  float m_run = 0.f, l_run = 0.f;
+  f16v nm;
+#pragma unroll
+  for (int r = 0; r < 16; r++) nm[r] = 0.f;
 
   const int vkey = (lane >> 1) & 7;  // swizzle key of V^T row (db*32 + l31)
 
-  // S^T = K . Q^T of one 64-key tile: two 32-key blocks
+  // S^T - ref = K . Q^T + (-ref) of one 64-key tile: two 32-key blocks
   auto qk = [&](int buf, f16v& s0, f16v& s1) {
     const char* sK = smem + buf * BUF_BYTES;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) {
       const h8 k0f = *(const h8*)(sK + ((l31)*KPITCH + ks * 2 + hi) * 16);
       const h8 k1f = *(const h8*)(sK + ((32 + l31) * KPITCH + ks * 2 + hi) * 16);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0f, qf[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1f, qf[ks], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0f, qf[ks], ks == 0 ? nm : s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1f, qf[ks], ks == 0 ? nm : s1, 0, 0, 0);
     }
   };
 
-  f16v sA[2], sB[2];  // score tiles: current and (NST == 3) the next one, ping-ponged by a 2x unrolled loop
-  int cur = 0;        // ring slot of tile t
-  if (NST == 2) {
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  } else {
-    stage(0, 0);
-    if (ntiles > 1) stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    qk(0, sA[0], sA[1]);
-  }
-  // one tile: [NST==3: issue the NEXT tile's QK^T MFMAs first so they run under this tile's softmax VALU work]
-  auto tile = [&](int t, f16v (&s)[2], f16v (&sn)[2]) {
-    if (NST == 2) {
-      if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-      qk(t & 1, s[0], s[1]);
-    } else {
-      if (t + 2 < ntiles) stage(t + 2, cur >= 1 ? cur - 1 : 2);  // slot of tile t-1 (free since the last barrier)
-    }
-    const char* sV = smem + (NST == 2 ? (t & 1) : cur) * BUF_BYTES + K_BYTES;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; t++) {
+    f16v s[2];
+    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+    qk(t & 1, s[0], s[1]);
+    asm volatile("" ::"v"(nm));  // a use after both first-k-step MFMAs: keeps them in the untied (dst != C) form, no copy of nm
+    const char* sV = smem + (t & 1) * BUF_BYTES + K_BYTES;
     // lane (hi, r) of block kb holds key kb*32 + (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
     if ((t + 1) * 64 > p.Sk) {
       const int k0 = t * 64;
@@ -219,56 +214,35 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
           if (k0 + kl >= p.Sk) s[kb][r] = -1.0e30f;
         }
     }
-    // ---- online softmax (fp32) ----------------------------------------------------------------
-    // NST == 3: the NEXT tile's S^T MFMAs are issued one at a time between pieces of this tile's softmax, in a pinned
-    // order, so the matrix pipe works while the VALU does max / exp2 (the last tile computes a dummy next tile).
-    h8 kf[NST == 3 ? KSTEPS : 1][2];
-    float mx;
-    if (NST == 3) {
-      const char* sKn = smem + (cur == 2 ? 0 : cur + 1) * BUF_BYTES;
+    float mx = s[0][0];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++) {
-        kf[ks][0] = *(const h8*)(sKn + ((l31)*KPITCH + ks * 2 + hi) * 16);
-        kf[ks][1] = *(const h8*)(sKn + ((32 + l31) * KPITCH + ks * 2 + hi) * 16);
-      }
-      const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      __builtin_amdgcn_sched_barrier(0);
-      sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[0], z, 0, 0, 0);
-      float m0 = s[0][0];
+    for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 1; r < 16; r++) m0 = fmaxf(m0, s[0][r]);
-      __builtin_amdgcn_sched_barrier(0);
-      sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[0], z, 0, 0, 0);
-      float m1 = s[1][0];
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (t == 0 || __any(mx > TSD_ATTN_LAZY)) {  // wave-uniform: move the reference (always on tile 0, then rarely)
+      const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_run += delta;
 #pragma unroll
-      for (int r = 1; r < 16; r++) m1 = fmaxf(m1, s[1][r]);
-      mx = fmaxf(m0, m1);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      mx = s[0][0];
+      for (int r = 0; r < 16; r++) nm[r] = -m_run;
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-    }
-    if (__any(mx > m_run)) {  // wave-uniform: rescale only when some row's running max actually grew
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-      m_run = m_new;
-      if (!ONES_ROW) l_run *= alpha;
-      const f2 a2 = {alpha, alpha};
+        for (int r = 0; r < 16; r++) s[kb][r] -= delta;
+      if (t != 0) {
+        if (!ONES_ROW) l_run *= alpha;
+        const f2 a2 = {alpha, alpha};
 #pragma unroll
-      for (int d = 0; d < DBLK; d++)
+        for (int d = 0; d < DBLK; d++)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          f2 v = {o[d][r], o[d][r + 1]};
-          v *= a2;
-          o[d][r] = v[0]; o[d][r + 1] = v[1];
-        }
+          for (int r = 0; r < 16; r += 2) {
+            f2 v = {o[d][r], o[d][r + 1]};
+            v *= a2;
+            o[d][r] = v[0]; o[d][r + 1] = v[1];
+          }
+      }
     }
-    const float nmc = -m_run * p.c;
     f2 psum2 = {0.f, 0.f};
     // P^T chunk kq (8 keys per lane) feeds the P.V MFMAs of chunk kq only, so the exponentials of chunk kq+1 are issued
     // between those MFMAs: the matrix pipe works through chunk kq while the VALU (exp2 is the slow part) produces the
@@ -278,10 +252,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
       const int kb = kq >> 1, r0 = (kq & 1) * 8;
 #pragma unroll
       for (int r = 0; r < 8; r += 2) {
-        // two v_fma_f32, not one v_pk_fma_f32: next to MFMAs the packed form costs more than it saves
-        // (scripts/micro/mfma_valu_overlap.hip: 64 pk_fma add 645 ns to 8 MFMAs, 64 v_fma_f32 add 155 ns)
-        const float e0 = fma1(s[kb][r0 + r], p.c, nmc), e1 = fma1(s[kb][r0 + r + 1], p.c, nmc);
-        const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+        const float p0 = __builtin_amdgcn_exp2f(s[kb][r0 + r]), p1 = __builtin_amdgcn_exp2f(s[kb][r0 + r + 1]);
         if (!ONES_ROW) psum2 += f2{p0, p1};
         pf[r] = (half_t)p0;
         pf[r + 1] = (half_t)p1;
@@ -294,29 +265,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     };
     h8 vf_cur[DBLK], vf_next[DBLK];
     v_frag(0, vf_cur);
-    h8 pf_cur;
-    if (NST == 3) {
-      constexpr int PER = (2 * KSTEPS - 2) / 4;  // remaining next-tile MFMAs per pair of exponentials
-      static_assert(NST != 3 || (2 * KSTEPS - 2) % 4 == 0, "next-tile MFMAs must split evenly over chunk 0");
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = i * PER; j < (i + 1) * PER; j++) {
-          const int ks = 1 + (j >> 1), blk = j & 1;
-          sn[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][blk], qf[ks], sn[blk], 0, 0, 0);
-        }
-        const int r = i * 2;
-        const float e0 = fma1(s[0][r], p.c, nmc), e1 = fma1(s[0][r + 1], p.c, nmc);
-        const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
-        if (!ONES_ROW) psum2 += f2{p0, p1};
-        pf_cur[r] = (half_t)p0;
-        pf_cur[r + 1] = (half_t)p1;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      pf_cur = p_chunk(0);
-    }
+    h8 pf_cur = p_chunk(0);
 #pragma unroll
     for (int kq = 0; kq < 4; kq++) {  // kq = kb*2 + half ; logical chunk = kq*2 + hi
       if (kq < 3) v_frag(kq + 1, vf_next);  // LDS latency hides under this chunk's MFMAs
@@ -334,11 +283,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
     if (!ONES_ROW) l_run += psum2[0] + psum2[1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur = (cur == 2) ? 0 : cur + 1;
-  };
-  for (int t = 0; t < ntiles; t += 2) {
-    tile(t, sA, sB);
-    if (t + 1 < ntiles) tile(t + 1, sB, sA);
   }
 #ifdef TSD_ATTN_TS
   if (threadIdx.x == 0 && ts_blk < 65536) { g_attn_ts[ts_blk * 4 + 1] = __builtin_amdgcn_s_memtime(); g_attn_ts[ts_blk * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
@@ -373,13 +317,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnK p) {
 }
 
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
-static int g_attn_nst = 2;  // schedule: 2 = double buffer (default; measured faster), 3 = QK(t+1) issued under softmax(t) (TSD_ATTN_NST=3)
-
-template <int D, int NST>
+template <int D>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
-  constexpr int LDS = NST * (64 * KPITCH * 16 + DBLK * 32 * 128);
-  auto fn = flash_attn_kernel<D, NST>;
+  constexpr int LDS = 2 * (64 * KPITCH * 16 + DBLK * 32 * 128);
+  auto fn = flash_attn_kernel<D>;
   static unsigned long long attr = 0;  // one bit per device
   if (!((attr >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -395,10 +337,6 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4) TSD_FAIL(TSD_E_SHAPE, "flash attention: misaligned pitches");
   if (a.Sq <= 0 || a.Sk <= 0) TSD_FAIL(TSD_E_SHAPE, "flash attention: empty sequence");
   if (!ctx->launch()) return TSD_OK;
-  {
-    static bool env_read = false;
-    if (!env_read) { const char* e = getenv("TSD_ATTN_NST"); if (e && (e[0] == '2' || e[0] == '3')) g_attn_nst = e[0] - '0'; env_read = true; }
-  }
   ProfScope prof(ctx, KC_ATTN, a.Sq, a.Sk, a.d, a.B * a.H);
   AttnK k;
   k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros; k.ones = ctx->zeros + 1024;
@@ -407,9 +345,9 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   k.H = a.H; k.Sq = a.Sq; k.Sk = a.Sk; k.Skv = std::min(round_up(a.Sk, 8), a.ldvt);
   k.c = a.scale * 1.4426950408889634f;
   switch (a.d) {
-    case 40: return g_attn_nst == 2 ? launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq) : launch_fa<40, 3>(ctx, k, a.B, a.H, a.Sq);
-    case 80: return g_attn_nst == 2 ? launch_fa<80, 2>(ctx, k, a.B, a.H, a.Sq) : launch_fa<80, 3>(ctx, k, a.B, a.H, a.Sq);
-    default: return launch_fa<160, 2>(ctx, k, a.B, a.H, a.Sq);
+    case 40: return launch_fa<40>(ctx, k, a.B, a.H, a.Sq);
+    case 80: return launch_fa<80>(ctx, k, a.B, a.H, a.Sq);
+    default: return launch_fa<160>(ctx, k, a.B, a.H, a.Sq);
   }
 }
 

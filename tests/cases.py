@@ -303,12 +303,15 @@ class _Mm2(_Mm):
 
 
 # ---- attention ------------------------------------------------------------------------------------------------
-def _sa_case(name, T, D, H, in_bias):
-    @case(name, tol=5e-3, tol_max=2e-2)
+def _sa_case(name, T, D, H, in_bias, ramp=None, tol=5e-3, tol_max=2e-2):
+    @case(name, tol=tol, tol_max=tol_max)
     class _S:
         @staticmethod
         def build():
-            return dict(x=randn(18, T, D), wi=_w(19, 3 * D, D), bi=randn(20, 3 * D) * 0.1 if in_bias else None,
+            x = randn(18, T, D)
+            if ramp is not None:  # token magnitudes grow (or shrink) along the sequence: the score maxima move from key tile to key tile
+                x = x * np.linspace(ramp[0], ramp[1], T, dtype=np.float32)[:, None]
+            return dict(x=x, wi=_w(19, 3 * D, D), bi=randn(20, 3 * D) * 0.1 if in_bias else None,
                         wo=_w(21, D, D), bo=randn(22, D) * 0.1)
 
         @staticmethod
@@ -330,6 +333,12 @@ _sa_case("self_attention_d80", 64, 640, 8, False)
 _sa_case("self_attention_d160", 64, 1280, 8, False)
 _sa_case("self_attention_d40_ragged", 72, 320, 8, False)   # Tq/Tk tails inside one 64-key tile + second tile
 _sa_case("self_attention_vae_1head", 64, 128, 1, True)     # VAE style: one head, biases on (unfused path)
+# The fused core keeps a lazily updated softmax reference (kernels_attn.hip, TSD_ATTN_LAZY): these rows make the running maximum
+# climb by tens of log2 units across five / six key tiles (and start far below / above zero), so the reference-move path runs.
+_sa_case("self_attention_d40_rising_scores", 320, 320, 8, False, ramp=(0.25, 2.5), tol=2e-2, tol_max=1.5e-1)
+_sa_case("self_attention_d40_falling_scores", 328, 320, 8, False, ramp=(2.5, 0.25), tol=2e-2, tol_max=1.5e-1)
+_sa_case("self_attention_d80_rising_scores", 200, 640, 8, False, ramp=(0.25, 2.5), tol=2e-2, tol_max=1.5e-1)
+_sa_case("self_attention_d160_rising_scores", 136, 1280, 8, False, ramp=(0.25, 2.5), tol=2e-2, tol_max=1.5e-1)
 
 
 def _ca_case(name, Tq, D, H, Tk=77, Dc=768):
