@@ -290,6 +290,10 @@ int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, i
                          int ref_cfg, float* max_abs_diff, float* max_abs_ref);
 /* Same for the fused attention core: Q,K [B][S][H*d], V^T [B][H*d][Sk]. */
 int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int iters, float* ms);
+/* The fused attention core runs an optimistic softmax pass (reference fixed after the first key tile) and repeats a
+ * workgroup exactly when one of its rows overflowed fp16: number of workgroups that repeated since the last reset
+ * (reset != 0 clears the counter); < 0 on error.  Synchronises the context's stream. */
+int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset);
 
 /* ---- census -------------------------------------------------------------------------- */
 /* Algorithmic GFLOP (2*MAC of conv + linear + attention core) of one forward per sample

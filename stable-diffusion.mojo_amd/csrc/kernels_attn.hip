@@ -24,6 +24,7 @@
 
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "lds_dma.h"
 
@@ -48,9 +49,14 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 #ifdef TSD_ATTN_TS
 __device__ unsigned long long g_attn_ts[4 * 65536];  // per block: memtime start/end, memrealtime start/end
 #endif
+__device__ unsigned g_attn_exact_wg;  // workgroups that had to run the exact pass (tsd_debug_attn_exact_passes)
 // Largest score (log2 units, relative to the running reference) a tile may reach before the reference is moved.
 // P = exp2(s - ref) is then at most 2^12 - far inside fp16 (65504) and harmless for the fp32 O / row-sum accumulators.
 #define TSD_ATTN_LAZY 12.0f
+// Optimistic pass: ref = (row maximum of tile 0) + this, so a later score may exceed tile 0's maximum by 16 + 4 = 20 log2 units
+// (13.9 nats) before an fp16 P overflows and the exact pass has to run; the largest P of tile 0 is then 2^-4, still 2^10
+// above the smallest normal fp16.
+#define TSD_ATTN_HEADROOM 4.0f
 
 template <int D>
 // min 2 waves/SIMD: caps the budget at 256 unified registers so the MFMA results stay in VGPRs (no v_accvgpr moves
@@ -165,21 +171,17 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
     *(h8*)(smem + buf * BUF_BYTES + K_BYTES + R * 128 + pos * 16) = h8{fill, fill, fill, fill, fill, fill, fill, fill};
   }
 
-  f16v o[DBLK];
-#pragma unroll
-  for (int d = 0; d < DBLK; d++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) o[d][r] = 0.f;
   // Online softmax with a LAZY reference: the exponent s - ref comes straight out of the QK^T MFMAs (ref enters as their
-  // C operand, a 16-register block holding -ref), and ref only moves when a tile's largest exponent exceeds
-  // TSD_ATTN_LAZY - after the first tile that is rare, so a tile's VALU work is max3, exp2 and the fp16 convert only.
-  // Tile 0 always sets ref to its exact row maximum (so every row has a P >= 2^-LAZY ... 1 term and the sum cannot
-  // underflow); afterwards ref >= (running max) - LAZY, P <= 2^LAZY.
-  float m_run = 0.f, l_run = 0.f;
+  // C operand, a 16-register block holding -ref).  Tile 0 sets ref to its exact row maximum (so every row has a P = 1
+  // term and the sum cannot underflow).  Two passes share the loop below:
+  //  * OPTIMISTIC (always run): ref never moves after tile 0 and no maximum is taken - a tile's VALU work is exp2 and
+  //    the fp16 convert only.  A later score more than 16 log2 units above ref makes its fp16 P infinite, which
+  //    poisons that row's sum (the ones row of V^T / the O accumulators): checked once, after the last tile.
+  //  * EXACT (only if some row of the workgroup overflowed): the whole workgroup runs again with the row maximum
+  //    taken per tile and ref moved whenever a tile exceeds it by TSD_ATTN_LAZY (P <= 2^LAZY, never overflows).
+  f16v o[DBLK];
+  float m_run, l_run;
   f16v nm;
-#pragma unroll
-  for (int r = 0; r < 16; r++) nm[r] = 0.f;
-
   const int vkey = (lane >> 1) & 7;  // swizzle key of V^T row (db*32 + l31)
 
   // S^T - ref = K . Q^T + (-ref) of one 64-key tile: two 32-key blocks
@@ -194,6 +196,15 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
     }
   };
 
+  auto run = [&](auto exact_c) {
+  constexpr bool EXACT = decltype(exact_c)::value;
+#pragma unroll
+  for (int d = 0; d < DBLK; d++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[d][r] = 0.f;
+  m_run = 0.f; l_run = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) nm[r] = 0.f;
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
           if (k0 + kl >= p.Sk) s[kb][r] = -1.0e30f;
         }
     }
+    if (EXACT || t == 0) {
     float mx = s[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (t == 0 || __any(mx > TSD_ATTN_LAZY)) {  // wave-uniform: move the reference (always on tile 0, then rarely)
-      const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+      const float delta = t == 0 ? mx + (EXACT ? 0.f : TSD_ATTN_HEADROOM) : fmaxf(mx, 0.f);
       const float alpha = __builtin_amdgcn_exp2f(-delta);
       m_run += delta;
 #pragma unroll
@@ -242,6 +254,7 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
             o[d][r] = v[0]; o[d][r + 1] = v[1];
           }
       }
+    }
     }
     f2 psum2 = {0.f, 0.f};
     // P^T chunk kq (8 keys per lane) feeds the P.V MFMAs of chunk kq only, so the exponentials of chunk kq+1 are issued
@@ -284,19 +297,44 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  };
+  // row sum l: row D of O^T when V^T carries the ones row (it sits in the hi=0 lane of each query's lane pair)
+  auto row_sum = [&]() {
+    if (ONES_ROW) {
+      const float lv = o[L_BLK][L_REG];
+      const float lo = __shfl_xor(lv, 32);
+      return hi ? lo : lv;
+    }
+    return l_run + __shfl_xor(l_run, 32);
+  };
+  run(std::false_type{});
+  float l_tot = row_sum();
+  {
+    bool bad = !(l_tot < 1.0e37f);  // inf or NaN
+    if (!ONES_ROW) {  // the fp32 sum of fp32 P cannot see an fp16 P that overflowed; O can
+      float amax = 0.f;
+#pragma unroll
+      for (int d = 0; d < DBLK; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(o[d][r]));  // NaN-dropping max: test inf, then NaN via the sum
+      float osum = 0.f;
+#pragma unroll
+      for (int d = 0; d < DBLK; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) osum += o[d][r] * 0.f;
+      bad = bad || !(amax < 1.0e37f) || osum != 0.f;
+    }
+    if (__syncthreads_or(bad)) {
+      if (tid == 0) atomicAdd(&g_attn_exact_wg, 1u);
+      run(std::true_type{});
+      l_tot = row_sum();
+    }
+  }
 #ifdef TSD_ATTN_TS
   if (threadIdx.x == 0 && ts_blk < 65536) { g_attn_ts[ts_blk * 4 + 1] = __builtin_amdgcn_s_memtime(); g_attn_ts[ts_blk * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
   // ---- normalise and store O[b][q][h*D + d] -----------------------------------------------------
-  float l_tot;
-  if (ONES_ROW) {  // row D of O^T = sum of P; it sits in the hi=0 lane of each query's lane pair
-    const float lv = o[L_BLK][L_REG];
-    const float lo = __shfl_xor(lv, 32);
-    l_tot = hi ? lo : lv;
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32);
-  }
   const float inv = 1.f / l_tot;
   const int qrow = q0 + l31;
   if (qrow < p.Sq) {
@@ -349,6 +387,16 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
     case 80: return launch_fa<80>(ctx, k, a.B, a.H, a.Sq);
     default: return launch_fa<160>(ctx, k, a.B, a.H, a.Sq);
   }
+}
+
+// Workgroups of flash_attn_kernel that ran the exact pass since the last reset (device-wide; synchronises the stream).
+extern "C" int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset) {
+  if (!ctx) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_exact_wg), sizeof(v)) != hipSuccess) return -1;
+  if (reset) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_exact_wg), &z, sizeof(z)) != hipSuccess) return -1; }
+  return (int)std::min(v, 0x7fffffffu);
 }
 
 // Debug/bench entry: time `iters` launches of the fused attention core on synthetic device data.

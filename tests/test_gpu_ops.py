@@ -78,3 +78,21 @@ def test_tile_configurations_are_bitwise_equivalent(gpu_ctx, tsd_mod, conv, B, H
         r = lib().tsd_debug_gemm_check(gpu_ctx.h, conv, B, H, H, Cin, N, stride, ups, cfg, ref, C.byref(d), C.byref(m))
         assert r == 0, f"cfg {cfg}: rc {r}"
         assert d.value == 0.0 and m.value > 0.0, f"cfg {cfg} differs from cfg {ref}: max|diff| {d.value} (max|ref| {m.value})"
+
+
+def test_attention_exact_pass_runs_only_when_a_row_overflows(gpu_ctx, tsd_mod):
+    """kernels_attn.hip runs the softmax optimistically (reference = first key tile's row maximum + 4, in log2 units) and
+    repeats a workgroup with the exact running maximum only if an fp16 probability overflowed.  Ordinary inputs must never
+    take the second pass; scores that climb by tens of log2 units along the keys must (and still match the oracle)."""
+    from tsd._lib import lib
+    L = lib()
+    assert L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1) >= 0
+    for name, expect_exact in (("self_attention_d40", False), ("self_attention_d40_falling_scores", False),
+                               ("self_attention_d40_rising_scores", True), ("self_attention_d80_rising_scores", True),
+                               ("self_attention_d160_rising_scores", True)):
+        c = CASES[name]
+        i = c.build()
+        y = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+        n = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+        assert (n > 0) == expect_exact, (name, n)
+        assert_close(y, np.asarray(c.oracle(i), dtype=np.float32), c.tol, c.tol_max, what=name)
