@@ -58,10 +58,15 @@ __device__ unsigned g_attn_exact_wg;  // workgroups that had to run the exact pa
 // above the smallest normal fp16.
 #define TSD_ATTN_HEADROOM 4.0f
 
-template <int D>
-// min 2 waves/SIMD: caps the budget at 256 unified registers so the MFMA results stay in VGPRs (no v_accvgpr moves
-// around the softmax / rescale VALU work).
-__global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const AttnK p) {
+// QB = 32-query blocks per wave.  Every K / V^T fragment read from LDS feeds QB MFMAs, and the LDS pipe is what bounds
+// QB = 1: one 1-KiB ds_read_b128 per 32x32x16 MFMA is 8 LDS cycles per 32 matrix-pipe cycles on each of 4 SIMDs - the
+// CU's whole LDS bandwidth, before the tile DMA writes.  QB = 2 (d = 40: 64 queries per wave, 256 per workgroup) halves
+// that at the price of 2 waves per SIMD instead of 4.
+// An (empty) use of a 16-register block.  A device function, so the host pass never sees the "v" constraint.
+__device__ __forceinline__ void keep_alive(const f16v& v) { asm volatile("" ::"v"(v)); }
+
+template <int D, int QB>
+__global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kernel(const AttnK p) {
   constexpr int NST = 2;                   // K / V^T tile buffers
   constexpr int DCH = D / 8;               // 16-B chunks per K row
   constexpr int KSTEPS = (DCH + 1) / 2;    // QK^T k-steps (16 wide)
@@ -93,27 +98,28 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
 
   const half_t* Qb = p.Q + b * p.sQ + h * D;
   const half_t* Kb = p.K + b * p.sK + h * D;
   const half_t* Vb = p.Vt + b * p.sVt + (long long)h * D * p.ldvt;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q][chunk ks*2+hi] -----------------
-  h8 qf[KSTEPS];
-  {
-    int qrow = q0 + l31;
+  h8 qf[QB][KSTEPS];
+#pragma unroll
+  for (int qb = 0; qb < QB; qb++) {
+    int qrow = q0 + qb * 32 + l31;
     if (qrow >= p.Sq) qrow = p.Sq - 1;
     const half_t* qp = Qb + (long long)qrow * p.ldq;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) {
       const int ch = ks * 2 + hi;
-      if (ch < DCH) qf[ks] = *(const h8*)(qp + ch * 8);
-      else qf[ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ch < DCH) qf[qb][ks] = *(const h8*)(qp + ch * 8);
+      else qf[qb][ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};
       // scale * log2(e) goes into Q once (fp32 multiply, one fp16 rounding), so the MFMA result is already the exponent
       // and the per-score v_fma_f32 of the softmax disappears
 #pragma unroll
-      for (int e = 0; e < 8; e++) qf[ks][e] = (half_t)((float)qf[ks][e] * p.c);
+      for (int e = 0; e < 8; e++) qf[qb][ks][e] = (half_t)((float)qf[qb][ks][e] * p.c);
     }
   }
 
@@ -172,47 +178,52 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
   }
 
   // Online softmax with a LAZY reference: the exponent s - ref comes straight out of the QK^T MFMAs (ref enters as their
-  // C operand, a 16-register block holding -ref).  Tile 0 sets ref to its exact row maximum (so every row has a P = 1
-  // term and the sum cannot underflow).  Two passes share the loop below:
+  // C operand, a 16-register block holding -ref).  Tile 0 sets ref from its exact row maximum (so the sum cannot
+  // underflow).  Two passes share the loop below:
   //  * OPTIMISTIC (always run): ref never moves after tile 0 and no maximum is taken - a tile's VALU work is exp2 and
   //    the fp16 convert only.  A later score more than 16 log2 units above ref makes its fp16 P infinite, which
   //    poisons that row's sum (the ones row of V^T / the O accumulators): checked once, after the last tile.
   //  * EXACT (only if some row of the workgroup overflowed): the whole workgroup runs again with the row maximum
   //    taken per tile and ref moved whenever a tile exceeds it by TSD_ATTN_LAZY (P <= 2^LAZY, never overflows).
-  f16v o[DBLK];
-  float m_run, l_run;
-  f16v nm;
+  f16v o[QB][DBLK];
+  float m_run[QB], l_run[QB];
+  f16v nm[QB];
   const int vkey = (lane >> 1) & 7;  // swizzle key of V^T row (db*32 + l31)
-
-  // S^T - ref = K . Q^T + (-ref) of one 64-key tile: two 32-key blocks
-  auto qk = [&](int buf, f16v& s0, f16v& s1) {
-    const char* sK = smem + buf * BUF_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) {
-      const h8 k0f = *(const h8*)(sK + ((l31)*KPITCH + ks * 2 + hi) * 16);
-      const h8 k1f = *(const h8*)(sK + ((32 + l31) * KPITCH + ks * 2 + hi) * 16);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0f, qf[ks], ks == 0 ? nm : s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1f, qf[ks], ks == 0 ? nm : s1, 0, 0, 0);
-    }
-  };
 
   auto run = [&](auto exact_c) {
   constexpr bool EXACT = decltype(exact_c)::value;
 #pragma unroll
-  for (int d = 0; d < DBLK; d++)
+  for (int qb = 0; qb < QB; qb++) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) o[d][r] = 0.f;
-  m_run = 0.f; l_run = 0.f;
+    for (int d = 0; d < DBLK; d++)
 #pragma unroll
-  for (int r = 0; r < 16; r++) nm[r] = 0.f;
+      for (int r = 0; r < 16; r++) o[qb][d][r] = 0.f;
+    m_run[qb] = 0.f; l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) nm[qb][r] = 0.f;
+  }
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < ntiles; t++) {
-    f16v s[2];
+    f16v s[QB][2];
     if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-    qk(t & 1, s[0], s[1]);
-    asm volatile("" ::"v"(nm));  // a use after both first-k-step MFMAs: keeps them in the untied (dst != C) form, no copy of nm
+    {  // S^T - ref = K . Q^T + (-ref) of one 64-key tile: two 32-key blocks per query block, K fragments read once
+      const char* sK = smem + (t & 1) * BUF_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        const h8 k0f = *(const h8*)(sK + ((l31)*KPITCH + ks * 2 + hi) * 16);
+        const h8 k1f = *(const h8*)(sK + ((32 + l31) * KPITCH + ks * 2 + hi) * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) {
+          s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0f, qf[qb][ks], ks == 0 ? nm[qb] : s[qb][0], 0, 0, 0);
+          s[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1f, qf[qb][ks], ks == 0 ? nm[qb] : s[qb][1], 0, 0, 0);
+        }
+      }
+    }
+    // a use after the first-k-step MFMAs: keeps them in the untied (dst != C) form, no copy of nm
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) keep_alive(nm[qb]);
     const char* sV = smem + (t & 1) * BUF_BYTES + K_BYTES;
     // lane (hi, r) of block kb holds key kb*32 + (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
     if ((t + 1) * 64 > p.Sk) {
@@ -222,55 +233,67 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int kl = kb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
-          if (k0 + kl >= p.Sk) s[kb][r] = -1.0e30f;
+          if (k0 + kl >= p.Sk) {
+#pragma unroll
+            for (int qb = 0; qb < QB; qb++) s[qb][kb][r] = -1.0e30f;
+          }
         }
     }
     if (EXACT || t == 0) {
-    float mx = s[0][0];
+      float mx[QB];
+      bool move = t == 0;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++)
+      for (int qb = 0; qb < QB; qb++) {
+        float m = s[qb][0][0];
 #pragma unroll
-      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (t == 0 || __any(mx > TSD_ATTN_LAZY)) {  // wave-uniform: move the reference (always on tile 0, then rarely)
-      const float delta = t == 0 ? mx + (EXACT ? 0.f : TSD_ATTN_HEADROOM) : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
-      m_run += delta;
+        for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) nm[r] = -m_run;
+          for (int r = 0; r < 16; r++) m = fmaxf(m, s[qb][kb][r]);
+        mx[qb] = fmaxf(m, __shfl_xor(m, 32));
+        move = move || mx[qb] > TSD_ATTN_LAZY;
+      }
+      if (__any(move)) {  // wave-uniform: move the reference (always on tile 0, then rarely)
 #pragma unroll
-      for (int kb = 0; kb < 2; kb++)
+        for (int qb = 0; qb < QB; qb++) {
+          const float delta = t == 0 ? mx[qb] + (EXACT ? 0.f : TSD_ATTN_HEADROOM) : fmaxf(mx[qb], 0.f);
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] += delta;
 #pragma unroll
-        for (int r = 0; r < 16; r++) s[kb][r] -= delta;
-      if (t != 0) {
-        if (!ONES_ROW) l_run *= alpha;
-        const f2 a2 = {alpha, alpha};
+          for (int r = 0; r < 16; r++) nm[qb][r] = -m_run[qb];
 #pragma unroll
-        for (int d = 0; d < DBLK; d++)
+          for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            f2 v = {o[d][r], o[d][r + 1]};
-            v *= a2;
-            o[d][r] = v[0]; o[d][r + 1] = v[1];
+            for (int r = 0; r < 16; r++) s[qb][kb][r] -= delta;
+          if (t != 0) {
+            if (!ONES_ROW) l_run[qb] *= alpha;
+            const f2 a2 = {alpha, alpha};
+#pragma unroll
+            for (int d = 0; d < DBLK; d++)
+#pragma unroll
+              for (int r = 0; r < 16; r += 2) {
+                f2 v = {o[qb][d][r], o[qb][d][r + 1]};
+                v *= a2;
+                o[qb][d][r] = v[0]; o[qb][d][r + 1] = v[1];
+              }
           }
+        }
       }
     }
-    }
-    f2 psum2 = {0.f, 0.f};
+    f2 psum2[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) psum2[qb] = f2{0.f, 0.f};
     // P^T chunk kq (8 keys per lane) feeds the P.V MFMAs of chunk kq only, so the exponentials of chunk kq+1 are issued
     // between those MFMAs: the matrix pipe works through chunk kq while the VALU (exp2 is the slow part) produces the
-    // next one.  The issue order is pinned; left to itself the compiler emits all 32 exponentials and then all MFMAs.
-    auto p_chunk = [&](int kq) {
-      h8 pf;
-      const int kb = kq >> 1, r0 = (kq & 1) * 8;
+    // next one.  The issue order is pinned; left to itself the compiler emits all the exponentials and then all MFMAs.
+    auto p_part = [&](int qb, int kq, int half, h8& pf) {  // 4 of the 8 probabilities of chunk kq
+      const int kb = kq >> 1, r0 = (kq & 1) * 8 + half * 4;
 #pragma unroll
-      for (int r = 0; r < 8; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(s[kb][r0 + r]), p1 = __builtin_amdgcn_exp2f(s[kb][r0 + r + 1]);
-        if (!ONES_ROW) psum2 += f2{p0, p1};
-        pf[r] = (half_t)p0;
-        pf[r + 1] = (half_t)p1;
+      for (int r = 0; r < 4; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s[qb][kb][r0 + r]), p1 = __builtin_amdgcn_exp2f(s[qb][kb][r0 + r + 1]);
+        if (!ONES_ROW) psum2[qb] += f2{p0, p1};
+        pf[half * 4 + r] = (half_t)p0;
+        pf[half * 4 + r + 1] = (half_t)p1;
       }
-      return pf;
     };
     auto v_frag = [&](int kq, h8 (&vf)[DBLK]) {
 #pragma unroll
@@ -278,56 +301,75 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
     };
     h8 vf_cur[DBLK], vf_next[DBLK];
     v_frag(0, vf_cur);
-    h8 pf_cur = p_chunk(0);
+    h8 pf_cur[QB], pf_next[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) { p_part(qb, 0, 0, pf_cur[qb]); p_part(qb, 0, 1, pf_cur[qb]); }
 #pragma unroll
     for (int kq = 0; kq < 4; kq++) {  // kq = kb*2 + half ; logical chunk = kq*2 + hi
       if (kq < 3) v_frag(kq + 1, vf_next);  // LDS latency hides under this chunk's MFMAs
       __builtin_amdgcn_sched_barrier(0);
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_cur[0], pf_cur, o[0], 0, 0, 0);
-      h8 pf_next = pf_cur;
-      if (kq < 3) pf_next = p_chunk(kq + 1);
+      // QB * DBLK MFMAs; the 2 * QB half-chunks of exponentials for chunk kq+1 are spread between them
+      constexpr int NM = QB * DBLK, NP = 2 * QB;
 #pragma unroll
-      for (int d = 1; d < DBLK; d++) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_cur[d], pf_cur, o[d], 0, 0, 0);
+      for (int i = 0; i < NM; i++) {
+        const int qb = i / DBLK, d = i - qb * DBLK;
+        o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_cur[d], pf_cur[qb], o[qb][d], 0, 0, 0);
+        if (kq < 3) {
+#pragma unroll
+          for (int j = (i * NP) / NM; j < ((i + 1) * NP) / NM; j++) p_part(j >> 1, kq + 1, j & 1, pf_next[j >> 1]);
+        }
+        if (QB > 1) __builtin_amdgcn_sched_barrier(0);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      pf_cur = pf_next;
+      if (kq < 3) {
 #pragma unroll
-      for (int d = 0; d < DBLK; d++) vf_cur[d] = vf_next[d];
+        for (int qb = 0; qb < QB; qb++) pf_cur[qb] = pf_next[qb];
+#pragma unroll
+        for (int d = 0; d < DBLK; d++) vf_cur[d] = vf_next[d];
+      }
     }
-    if (!ONES_ROW) l_run += psum2[0] + psum2[1];
+    if (!ONES_ROW) {
+#pragma unroll
+      for (int qb = 0; qb < QB; qb++) l_run[qb] += psum2[qb][0] + psum2[qb][1];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   };
   // row sum l: row D of O^T when V^T carries the ones row (it sits in the hi=0 lane of each query's lane pair)
-  auto row_sum = [&]() {
-    if (ONES_ROW) {
-      const float lv = o[L_BLK][L_REG];
+  auto row_sum = [&](int qb) {
+    if constexpr (ONES_ROW) {
+      const float lv = o[qb][L_BLK][L_REG];
       const float lo = __shfl_xor(lv, 32);
       return hi ? lo : lv;
     }
-    return l_run + __shfl_xor(l_run, 32);
+    return l_run[qb] + __shfl_xor(l_run[qb], 32);
   };
   run(std::false_type{});
-  float l_tot = row_sum();
+  float l_tot[QB];
   {
-    bool bad = !(l_tot < 1.0e37f);  // inf or NaN
-    if (!ONES_ROW) {  // the fp32 sum of fp32 P cannot see an fp16 P that overflowed; O can
-      float amax = 0.f;
+    bool bad = false;
 #pragma unroll
-      for (int d = 0; d < DBLK; d++)
+    for (int qb = 0; qb < QB; qb++) {
+      l_tot[qb] = row_sum(qb);
+      bad = bad || !(l_tot[qb] < 1.0e37f);  // inf or NaN
+      if (!ONES_ROW) {  // the fp32 sum of fp32 P cannot see an fp16 P that overflowed; O can
+        float amax = 0.f, osum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(o[d][r]));  // NaN-dropping max: test inf, then NaN via the sum
-      float osum = 0.f;
+        for (int d = 0; d < DBLK; d++)
 #pragma unroll
-      for (int d = 0; d < DBLK; d++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) osum += o[d][r] * 0.f;
-      bad = bad || !(amax < 1.0e37f) || osum != 0.f;
+          for (int r = 0; r < 16; r++) {
+            amax = fmaxf(amax, fabsf(o[qb][d][r]));  // NaN-dropping max finds inf; 0 * x finds NaN
+            osum += o[qb][d][r] * 0.f;
+          }
+        bad = bad || !(amax < 1.0e37f) || osum != 0.f;
+      }
     }
     if (__syncthreads_or(bad)) {
       if (tid == 0) atomicAdd(&g_attn_exact_wg, 1u);
       run(std::true_type{});
-      l_tot = row_sum();
+#pragma unroll
+      for (int qb = 0; qb < QB; qb++) l_tot[qb] = row_sum(qb);
     }
   }
 #ifdef TSD_ATTN_TS
@@ -335,37 +377,41 @@ __global__ __launch_bounds__(256, D == 40 ? 4 : 2) void flash_attn_kernel(const 
 #endif
 
   // ---- normalise and store O[b][q][h*D + d] -----------------------------------------------------
-  const float inv = 1.f / l_tot;
-  const int qrow = q0 + l31;
-  if (qrow < p.Sq) {
-    half_t* op = p.O + b * p.sO + (long long)qrow * p.ldo + h * D;
 #pragma unroll
-    for (int d = 0; d < DBLK; d++)
+  for (int qb = 0; qb < QB; qb++) {
+    const float inv = 1.f / l_tot[qb];
+    const int qrow = q0 + qb * 32 + l31;
+    if (qrow < p.Sq) {
+      half_t* op = p.O + b * p.sO + (long long)qrow * p.ldo + h * D;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const int dbase = d * 32 + 8 * g4 + 4 * hi;
-        if (dbase < D) {
-          h4 v;
+      for (int d = 0; d < DBLK; d++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[r] = (half_t)(o[d][g4 * 4 + r] * inv);
-          *(h4*)(op + dbase) = v;
+        for (int g4 = 0; g4 < 4; g4++) {
+          const int dbase = d * 32 + 8 * g4 + 4 * hi;
+          if (dbase < D) {
+            h4 v;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = (half_t)(o[qb][d][g4 * 4 + r] * inv);
+            *(h4*)(op + dbase) = v;
+          }
         }
-      }
+    }
   }
 }
 
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
-template <int D>
+static int g_attn_qb = 2;  // d = 40: 32-query blocks per wave (TSD_ATTN_QB=1 selects the 128-query workgroup)
+template <int D, int QB>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
   constexpr int LDS = 2 * (64 * KPITCH * 16 + DBLK * 32 * 128);
-  auto fn = flash_attn_kernel<D>;
+  auto fn = flash_attn_kernel<D, QB>;
   static unsigned long long attr = 0;  // one bit per device
   if (!((attr >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr |= 1ull << (ctx->device & 63);
   }
-  hipLaunchKernelGGL(fn, dim3(ceil_div(Sq, 128), B * H), dim3(256), LDS, ctx->stream, k);
+  hipLaunchKernelGGL(fn, dim3(ceil_div(Sq, 128 * QB), B * H), dim3(256), LDS, ctx->stream, k);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -375,6 +421,10 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4) TSD_FAIL(TSD_E_SHAPE, "flash attention: misaligned pitches");
   if (a.Sq <= 0 || a.Sk <= 0) TSD_FAIL(TSD_E_SHAPE, "flash attention: empty sequence");
   if (!ctx->launch()) return TSD_OK;
+  {
+    static bool env_read = false;
+    if (!env_read) { const char* e = getenv("TSD_ATTN_QB"); if (e && (e[0] == '1' || e[0] == '2')) g_attn_qb = e[0] - '0'; env_read = true; }
+  }
   ProfScope prof(ctx, KC_ATTN, a.Sq, a.Sk, a.d, a.B * a.H);
   AttnK k;
   k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros; k.ones = ctx->zeros + 1024;
@@ -383,9 +433,15 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   k.H = a.H; k.Sq = a.Sq; k.Sk = a.Sk; k.Skv = std::min(round_up(a.Sk, 8), a.ldvt);
   k.c = a.scale * 1.4426950408889634f;
   switch (a.d) {
-    case 40: return launch_fa<40>(ctx, k, a.B, a.H, a.Sq);
-    case 80: return launch_fa<80>(ctx, k, a.B, a.H, a.Sq);
-    default: return launch_fa<160>(ctx, k, a.B, a.H, a.Sq);
+    case 40:
+      // 64 queries per wave when that still fills the chip (2 workgroups per CU resident) and the key loop is long enough
+      // to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (shader clock 1.21 -> 1.46 GHz: the call is power-bound and
+      // half the LDS reads is what buys the clock); 77-key cross attention is better off with the 128-query workgroup
+      if (g_attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.B * a.H >= 512)
+        return launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq);
+      return launch_fa<40, 1>(ctx, k, a.B, a.H, a.Sq);
+    case 80: return launch_fa<80, 1>(ctx, k, a.B, a.H, a.Sq);
+    default: return launch_fa<160, 1>(ctx, k, a.B, a.H, a.Sq);
   }
 }
 
