@@ -309,6 +309,19 @@ def main():
                 sec[cls] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(gbs / 8000.0, 4), "ms_per_step": round(ms_c, 4)}
         roofline["secondary_kernels"] = sec
+        # What the matrix pipe of THIS board sustains (register-resident fp16 MFMA loop, ~20 ms, after the timed region): the
+        # nominal 2.5 PF assumes the boost clock, under MFMA load the power limit sets the clock.  `frac` above stays priced
+        # against the nominal peak; this is context for reading it.
+        try:
+            import ctypes as _C
+            _tf, _ghz = _C.c_float(), _C.c_float()
+            if _tsd_lib().tsd_debug_mfma_sustained(ctx.h, 20.0, _C.byref(_tf), _C.byref(_ghz)) == 0:
+                roofline["mfma_sustained_probe"] = {
+                    "tflops": round(_tf.value, 1), "shader_clock_ghz": round(_ghz.value, 3), "unit": "TFLOP/s",
+                    "frac_of_sustained": round(achieved / _tf.value, 4) if _tf.value > 0 else None,
+                    "what": "dense v_mfma_f32_16x16x32_f16 loop from registers, 4 waves/SIMD, no LDS or memory traffic"}
+        except Exception as e:  # a probe must never cost the bench line
+            roofline["mfma_sustained_probe"] = {"error": str(e)}
         # ---- VAE decode time (images/s end-to-end = B / (50 * step + decode)) ----
         dec_ms = None
         if dec is not None:

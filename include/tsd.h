@@ -294,6 +294,10 @@ int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int 
  * workgroup exactly when one of its rows overflowed fp16: number of workgroups that repeated since the last reset
  * (reset != 0 clears the counter); < 0 on error.  Synchronises the context's stream. */
 int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset);
+/* What this board sustains on the matrix pipe: a register-resident dense fp16 MFMA loop (no LDS, no memory) run for about
+ * `ms_target` ms at 4 waves per SIMD; reports the achieved TFLOP/s and the shader clock (GHz) during the run.  The nominal
+ * dense peak assumes the boost clock; under matrix-pipe load the board's power limit sets the clock. */
+int tsd_debug_mfma_sustained(tsd_ctx* ctx, float ms_target, float* tflops, float* clock_ghz);
 
 /* ---- census -------------------------------------------------------------------------- */
 /* Algorithmic GFLOP (2*MAC of conv + linear + attention core) of one forward per sample

@@ -1201,3 +1201,63 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   }
   return a.conv ? dispatch<true>(ctx, k, a.batch) : dispatch<false>(ctx, k, a.batch);
 }
+
+// ---- what this board sustains: register-resident dense fp16 MFMA loop (no LDS, no memory) ------------------------------
+// 4 waves per SIMD, each issuing independent v_mfma_f32_16x16x32_f16 back to back on pseudo-random operands, for about
+// `ms_target` milliseconds.  Reports the achieved TFLOP/s and the shader clock during the run (s_memtime ticks against the
+// 100 MHz s_memrealtime).  The dense peak of MI355X_MICROARCH.md (2.5 PF) assumes the 2.4 GHz boost clock; under a
+// matrix-pipe load the board's power limit sets the clock, and this is the ceiling the GEMM-class kernels can be priced
+// against in practice (bench.py reports it next to, never instead of, the nominal peak).
+__device__ unsigned long long g_probe_ts[4];
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* sink, int iters, unsigned seed) {
+  typedef _Float16 ph8 __attribute__((ext_vector_type(8)));
+  typedef float pf4 __attribute__((ext_vector_type(4)));
+  ph8 a[2], b;
+  unsigned s = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s = s * 1664525u + 1013904223u; a[i][e] = (_Float16)(((int)(s >> 20) - 2048) * (1.f / 2048.f)); }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { s = s * 1664525u + 1013904223u; b[e] = (_Float16)(((int)(s >> 20) - 2048) * (1.f / 2048.f)); }
+  pf4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_probe_ts[0] = __builtin_amdgcn_s_memtime(); g_probe_ts[2] = __builtin_amdgcn_s_memrealtime(); }
+  for (int it = 0; it < iters; it += 4) {  // 32 MFMAs per trip on two accumulators; the 4 waves of a SIMD interleave
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b, acc1, 0, 0, 0);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_probe_ts[1] = __builtin_amdgcn_s_memtime(); g_probe_ts[3] = __builtin_amdgcn_s_memrealtime(); }
+  float r = acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc1[0] + acc1[1] + acc1[2] + acc1[3];
+  if (r == 1234.5678f) sink[threadIdx.x] = r;  // keeps the loop alive; practically never true
+}
+
+extern "C" int tsd_debug_mfma_sustained(tsd_ctx* ctx, float ms_target, float* tflops, float* clock_ghz) {
+  if (!ctx || !tflops || !clock_ghz || !(ms_target > 0.f) || ms_target > 1000.f) TSD_FAIL(TSD_E_ARG, "mfma_sustained: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+  const int blocks = prop.multiProcessorCount * 4;  // 4 workgroups of 4 waves per CU = 4 waves per SIMD
+  TSD_TRY(ctx_reserve_arena(ctx, 4096));
+  float* sink = (float*)ctx->arena.base;
+  int iters = 2000;  // x 8 MFMAs per wave
+  float ms = 0.f;
+  for (int pass = 0; pass < 3; pass++) {  // pass 0 calibrates, pass 1 warms the board up to its power state, pass 2 is reported
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters, 12345u + pass);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (pass == 0) { iters = (int)std::min(50.0e6, std::max(100.0, iters * (double)ms_target / std::max(ms, 1e-3f))); iters = (iters + 3) & ~3; }
+  }
+  unsigned long long ts[4];
+  HIP_TRY(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_probe_ts), sizeof(ts)));
+  const double flop = (double)blocks * 4 /*waves*/ * (double)iters * 8 * (2.0 * 16 * 16 * 32);
+  *tflops = (float)(flop / (ms * 1e-3) / 1e12);
+  const double dr = (double)(ts[3] - ts[2]) * 10.0;  // ns
+  *clock_ghz = dr > 0 ? (float)((double)(ts[1] - ts[0]) / dr) : 0.f;
+  return TSD_OK;
+}

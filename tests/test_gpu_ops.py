@@ -96,3 +96,16 @@ def test_attention_exact_pass_runs_only_when_a_row_overflows(gpu_ctx, tsd_mod):
         n = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
         assert (n > 0) == expect_exact, (name, n)
         assert_close(y, np.asarray(c.oracle(i), dtype=np.float32), c.tol, c.tol_max, what=name)
+
+
+def test_mfma_sustained_probe_reports_a_plausible_ceiling(gpu_ctx):
+    """tsd_debug_mfma_sustained: register-resident fp16 MFMA loop; the figure bench.py prints next to the nominal 2.5 PF."""
+    import ctypes as C
+    from tsd._lib import lib
+    tf, ghz = C.c_float(), C.c_float()
+    assert lib().tsd_debug_mfma_sustained(gpu_ctx.h, 5.0, C.byref(tf), C.byref(ghz)) == 0
+    assert 500.0 < tf.value < 2600.0, tf.value       # cannot exceed the nominal dense peak
+    assert 0.8 < ghz.value < 2.6, ghz.value
+    # cycles: 1024 SIMDs x 1024 flop/clk at that clock bounds it from above (block 0's clock sample, so allow 15 %)
+    assert tf.value <= 1.15 * 1024 * 1024 * ghz.value * 1e9 / 1e12
+    assert lib().tsd_debug_mfma_sustained(gpu_ctx.h, -1.0, C.byref(tf), C.byref(ghz)) != 0
