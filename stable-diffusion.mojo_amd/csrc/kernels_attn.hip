@@ -400,7 +400,13 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
 }
 
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
-static int g_attn_qb = 2;  // d = 40: 32-query blocks per wave (TSD_ATTN_QB=1 selects the 128-query workgroup)
+static int g_attn_qb = 2;     // d = 40: 32-query blocks per wave (TSD_ATTN_QB=1 selects the 128-query workgroup)
+static int g_attn_qb_force = 0;  // tsd_debug_set_attn_qb: 0 = by shape, 1 / 2 = that many query blocks per wave whenever d = 40
+extern "C" int tsd_debug_set_attn_qb(int mode) {
+  const int prev = g_attn_qb_force;
+  if (mode >= 0 && mode <= 2) g_attn_qb_force = mode;
+  return prev;
+}
 template <int D, int QB>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
@@ -437,7 +443,7 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
       // 64 queries per wave when that still fills the chip (2 workgroups per CU resident) and the key loop is long enough
       // to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (shader clock 1.21 -> 1.46 GHz: the call is power-bound and
       // half the LDS reads is what buys the clock); 77-key cross attention is better off with the 128-query workgroup
-      if (g_attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.B * a.H >= 512)
+      if (g_attn_qb_force ? g_attn_qb_force == 2 : (g_attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.B * a.H >= 512))
         return launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq);
       return launch_fa<40, 1>(ctx, k, a.B, a.H, a.Sq);
     case 80: return launch_fa<80, 1>(ctx, k, a.B, a.H, a.Sq);

@@ -109,3 +109,32 @@ def test_mfma_sustained_probe_reports_a_plausible_ceiling(gpu_ctx):
     # cycles: 1024 SIMDs x 1024 flop/clk at that clock bounds it from above (block 0's clock sample, so allow 15 %)
     assert tf.value <= 1.15 * 1024 * 1024 * ghz.value * 1e9 / 1e12
     assert lib().tsd_debug_mfma_sustained(gpu_ctx.h, -1.0, C.byref(tf), C.byref(ghz)) != 0
+
+
+def test_attention_64_queries_per_wave_is_bitwise_the_128_query_workgroup(gpu_ctx, tsd_mod):
+    """flash_attn_kernel<40, 2> (64 queries per wave, picked for long key loops on big grids) against <40, 1>: in the
+    optimistic pass every row goes through the same instruction sequence, so the outputs must be identical bit for bit,
+    ragged lengths included.  In the exact repeat the decision to move the softmax reference is taken per wave (any of
+    its rows), so there the two only agree to rounding; both must match the oracle."""
+    from tsd._lib import lib
+    L = lib()
+    prev = L.tsd_debug_set_attn_qb(1)
+    L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+    try:
+        for name in ("self_attention_d40", "self_attention_d40_ragged", "self_attention_d40_rising_scores",
+                     "self_attention_d40_falling_scores", "cross_attention_d40_T77"):
+            c = CASES[name]
+            i = c.build()
+            L.tsd_debug_set_attn_qb(1)
+            y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+            L.tsd_debug_set_attn_qb(2)
+            y2 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+            if "rising" in name:
+                assert L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1) > 0
+                assert_close(y2, y1, 1e-3, 1e-2, what=name + " (QB=2 vs QB=1, exact repeat)")  # fp16 P rounds differently once the reference moves
+            else:
+                assert L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1) == 0
+                np.testing.assert_array_equal(y1, y2, err_msg=name)
+            assert_close(y2, np.asarray(c.oracle(i), dtype=np.float32), c.tol, c.tol_max, what=name + " (QB=2)")
+    finally:
+        L.tsd_debug_set_attn_qb(prev)
