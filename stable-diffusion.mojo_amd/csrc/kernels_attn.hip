@@ -7,19 +7,25 @@
 // leaves registers).
 //
 // Design (CDNA4, wave64):
-//   * one wave owns 32 query rows; a 4-wave workgroup shares each 64-key K / V^T tile through LDS
-//     (global_load_lds_dwordx4 DMA, double-buffered, one barrier per tile).
+//   * one wave owns QB x 32 query rows (QB = 2 at d = 40 for long key loops, else 1); a 4-wave workgroup shares each
+//     64-key K / V^T tile through LDS (descriptor LDS-DMA, double-buffered, one barrier per tile).
 //   * S^T = K . Q^T with v_mfma_f32_32x32x16_f16 ("swapped QK^T"): every lane then holds 32 of
 //     the 64 scores of ONE query row, so the row max/sum are in-lane plus a single lane^32
 //     exchange, and the O rescale is lane-local.
+//   * softmax without per-score arithmetic: scale*log2(e) is folded into the Q fragments and -ref is the C operand of
+//     the QK^T MFMAs, so the accumulator already holds the exponent; an optimistic pass keeps ref fixed after key tile 0
+//     and takes no maximum (exp2 + fp16 convert per score), an exact pass repeats a workgroup only if an fp16 P
+//     overflowed (see the comment at `run`).
 //   * O^T = V^T . P^T: P is consumed straight from registers as the MFMA B operand.  The K rows
 //     are loaded in a bit-2/bit-3-swapped order so that the 8 probabilities a lane owns per
 //     k-step are 8 CONSECUTIVE keys -> the V^T operand is one ds_read_b128.
 //   * V is consumed transposed ([channel][token], produced that way by the projection GEMM with
 //     swapped operands) so both operands are K-contiguous; no transposing LDS reads needed.
-//   * head dims that are not a multiple of 16 (d=40) are zero-padded per 16-B chunk by pointing the
-//     DMA source at a zero page; LDS row pitches are odd multiples of 16 B (K) / XOR-swizzled (V^T)
+//   * head dims that are not a multiple of 16 (d=40) are zero-padded per 16-B chunk by the DMA's range check /
+//     a padded offset; LDS row pitches are odd multiples of 16 B (K) / XOR-swizzled (V^T)
 //     so all ds_read_b128 are bank-conflict-free.
+//   * the 4096 x 4096 d = 40 call is power-bound (shader clock 1.2-1.5 GHz under it, profiles/r02_flash_clock.txt):
+//     what pays is fewer LDS reads and fewer VALU ops, not issue slots.
 #include <stdlib.h>
 
 #include <vector>
