@@ -96,7 +96,13 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // while one group issues its 2*FM*FN MFMAs of K-tile t the other group reads its fragments of the next tile from LDS
 // and issues DMA, so each SIMD's matrix pipe always has a wave feeding it.  Two barriers per K-tile separate the
 // phases; K-tiles are DMA'd three ahead into a 3-slot ring behind counted s_waitcnt vmcnt.
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false>
+// HX ("halo in x", conv3x3 stride 1, 128-row tiles, 2-slot ring): K is visited as (kh, channel chunk, kw) and the A operand
+// of the three kw taps of a (kh, chunk) group is ONE staged tile of the tile's pixels plus a left / right halo pixel per
+// image row (BM + 2 rows per image row segment); the kw taps read it at a row offset of kw.  The input pixels cross the
+// L2 -> CU path three times per channel chunk instead of nine: 71 -> 100 flop per L2 byte for the 128x160 tile, and that
+// path is what bounds these convs.  The W ring keeps its 2 slots; the A tiles live in two buffers of
+// their own (a group's tile must outlive three ring rotations).
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false, bool HX = false>
 __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * FN <= 20 ? 2 : 1)) void gemm_kernel(const GemmK p) {
   constexpr int NW = WGM * WGN;
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
@@ -104,6 +110,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   constexpr int A_INSTR = BM / 8, W_INSTR = BN / 8;  // 1-KiB wave-instructions per tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, W_PW = (W_INSTR + NW - 1) / NW;
   constexpr int TILE_BYTES = (BM + BN) * 128;
+  static_assert(!HX || (CONV && NS == 2 && !PP && NW == 4 && BM == 128 && BMw == 64), "halo-x: 128-row conv tiles, 2x2 waves, 2-slot ring");
+  constexpr int WB = BN * 128;                              // HX: bytes of a ring slot (W tile only)
+  constexpr int AH_INSTR = BM / 8 + 1, AB = AH_INSTR * 1024;  // HX: halo tile = BM + 2*nr rows (<= BM + 8), two buffers after the ring
+  constexpr int A_PWX = HX ? (AH_INSTR + NW - 1) / NW : A_PW;  // A DMA instructions per wave and staged tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   TS_MARK(0);
@@ -153,16 +163,27 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // ---- per-thread source offsets ---------------------------------------------------------
   // 32-bit BYTE offsets from the (wave-uniform) descriptor bases; the K position goes in the scalar offset, so a
   // DMA instruction costs no address VALU at all (every operand slice on the path is < 2 GiB, checked by the host).
-  unsigned a_off[A_PW];   // dense: row offset in the first source
-  unsigned a_off1[A_PW];  // dense: row offset in the second concat source ; conv: current tap offset (PAD_OFF = zero tap)
-  unsigned a_pk[A_PW];    // conv: (oy*stride-pad+1) | (ox*stride-pad+1) << 11 | b << 22   (b = 1023: row beyond M)
+  unsigned a_off[A_PWX];   // dense: row offset in the first source
+  unsigned a_off1[A_PWX];  // dense: row offset in the second concat source ; conv: current tap offset (PAD_OFF = zero tap)
+  unsigned a_pk[A_PWX];    // conv: (oy*stride-pad+1) | (ox*stride-pad+1) << 11 | b << 22   (b = 1023: row beyond M)
+  // HX geometry (wave-uniform): the tile is nr = 128 / seg image-row segments of seg = min(Wo, 128) pixels
+  const int hx_seg = HX ? (p.Wo < 128 ? p.Wo : 128) : 1;
 #pragma unroll
-  for (int i = 0; i < A_PW; i++) {
+  for (int i = 0; i < A_PWX; i++) {
     const int row = (wave + i * NW) * 8 + lrow;
     int m = m0 + row;
     const bool ok = m < p.M;
     if (!ok) m = p.M - 1;
-    if constexpr (!CONV) {
+    if constexpr (HX) {
+      // halo tile row R: image-row segment ir, column c in -1 .. seg (the two ends are the halo pixels)
+      const int ir = row / (hx_seg + 2), c = row - ir * (hx_seg + 2) - 1;
+      const bool valid = row < BM + 2 * (BM / hx_seg);
+      const int hw = p.Ho * p.Wo, b = m0 / hw, rem = m0 - b * hw;
+      const int oy = rem / p.Wo + ir, ox = rem - (rem / p.Wo) * p.Wo + c;
+      a_pk[i] = (unsigned)(oy + 1) | (unsigned)(ox + 1) << 11 | (valid ? (unsigned)b : 1023u) << 22;  // input row of tap kh: oy + kh - 1
+      a_off[i] = 0;
+      a_off1[i] = PAD_OFF;
+    } else if constexpr (!CONV) {
       a_off[i] = ((unsigned)m * (unsigned)p.lda0 + cch * 8) * 2;
       a_off1[i] = ((unsigned)m * (unsigned)p.lda1 + cch * 8) * 2;
       a_pk[i] = 0;
@@ -188,7 +209,18 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // conv: running (tap, channel-chunk) of the NEXT tile to stage
   const int cpt = CONV ? (p.Cin >> 6) : 1;
   int st_tap = kt0 / cpt, st_cc = kt0 - (kt0 / cpt) * cpt;
+  int st_kw = 0, st_g = 0;  // HX: (st_tap = kh, st_cc = chunk, st_kw) of the next tile to stage; st_g = its (kh, chunk) group number
   auto conv_tap_ptrs = [&](int tap) {
+    if constexpr (HX) {  // tap = kh: source offsets of the halo tile rows
+#pragma unroll
+      for (int i = 0; i < A_PWX; i++) {
+        const int iy = (int)(a_pk[i] & 2047u) - 1 + tap - 1, ix = (int)((a_pk[i] >> 11) & 2047u) - 1;
+        const unsigned b = a_pk[i] >> 22;
+        const bool ok = b != 1023u && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+        a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + iy) * p.Ws + ix) * (unsigned)p.lda0 + cch * 8) * 2 : PAD_OFF;
+      }
+      return;
+    }
     const int kh = tap / 3, kw = tap - kh * 3;
     const int Heff = p.ups ? 2 * p.Hs : p.Hs, Weff = p.ups ? 2 * p.Ws : p.Ws;
 #pragma unroll
@@ -207,7 +239,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // the MFMAs; stage_advance() steps the conv (tap, chunk) cursor.  `live` = false builds descriptors with zero
   // records: every lane is out of range and the DMA writes zeros, which lets the loop tail keep the same
   // straight-line body instead of branching around the DMA.
-  struct TileSrc { rsrc_t ra, rw; unsigned a_soff, w_soff; bool second; };
+  struct TileSrc { rsrc_t ra, rw; unsigned a_soff, w_soff; bool second; bool a_on; int abuf; };
   auto tile_src = [&](int kt, bool live) {
     TileSrc t;
     const int nrec = live ? 0x7ffffff0 : 0;
@@ -222,25 +254,43 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     }
     t.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Wt), 0, nrec, 0x00020000);
     t.w_soff = k0 * 2;
+    t.a_on = true; t.abuf = 0;
+    if constexpr (HX) {
+      t.w_soff = (unsigned)((st_tap * 3 + st_kw) * p.Cin + st_cc * 64) * 2;
+      t.a_on = st_kw == 0;  // the group's halo tile travels with its first tap
+      t.abuf = st_g & 1;
+    }
     return t;
   };
   auto stage_piece = [&](const TileSrc& t, int buf, int i) {
-    char* sA = smem + buf * TILE_BYTES;
-    char* sW = sA + BM * 128;
-    if (i < A_PW) {
+    char* sA = HX ? smem + NS * WB + t.abuf * AB : smem + buf * TILE_BYTES;
+    char* sW = HX ? smem + buf * WB : sA + BM * 128;
+    if (i < A_PWX) {
       const int j = wave + i * NW;
-      if (A_INSTR % NW == 0 || j < A_INSTR) {
+      if constexpr (HX) {
+        if (t.a_on && j < AH_INSTR) blds16(t.ra, a_off1[i], t.a_soff, sA + j * 1024);
+      } else if (A_INSTR % NW == 0 || j < A_INSTR) {
         if constexpr (!CONV) blds16(t.ra, t.second ? a_off1[i] : a_off[i], t.a_soff, sA + j * 1024);
         else blds16(t.ra, a_off1[i], t.a_soff, sA + j * 1024);
       }
     } else {
-      const int iw = i - A_PW;
+      const int iw = i - A_PWX;
       const int j = wave + iw * NW;
       if (W_INSTR % NW == 0 || j < W_INSTR) blds16(t.rw, w_off[iw], t.w_soff, sW + j * 1024);
     }
   };
   auto stage_advance = [&]() {
-    if constexpr (CONV) {
+    if constexpr (HX) {
+      if (++st_kw == 3) {
+        st_kw = 0;
+        ++st_g;
+        if (++st_cc == cpt) {
+          st_cc = 0;
+          ++st_tap;
+          if (st_tap < 3) conv_tap_ptrs(st_tap);
+        }
+      }
+    } else if constexpr (CONV) {
       if (++st_cc == cpt) {
         st_cc = 0;
         ++st_tap;
@@ -251,7 +301,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   auto stage = [&](int kt, int buf) {
     const TileSrc t = tile_src(kt, true);
 #pragma unroll
-    for (int i = 0; i < A_PW + W_PW; i++) stage_piece(t, buf, i);
+    for (int i = 0; i < A_PWX + W_PW; i++) stage_piece(t, buf, i);
     stage_advance();
   };
 
@@ -287,8 +337,24 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   // whole-K-tile fragment set in registers (pinned-order and ping-pong schedules)
   constexpr bool PIN = !PP && (NS <= TSD_GEMM_PIN_MAXNS) && (FM * FN * 4 + 8 * (FM + FN) + 56 <= 256) && (TSD_GEMM_PIN != 0);
   h8 af[2][(PIN || PP) ? FM : 1], wf[2][(PIN || PP) ? FN : 1];
+  static_assert(!HX || PIN, "halo-x runs the pinned schedule");
+  int c_kw = 0, c_g = 0;  // HX: kw and group number of the tile being multiplied
+  const int hx_base = HX ? wm * BMw + 2 * ((wm * BMw) / hx_seg) : 0;  // halo-tile row of this wave's first pixel at kw = 0 (its left halo)
   auto read_frags = [&](int buf) {
-    if constexpr (PIN || PP) {
+    if constexpr (HX) {
+      const char* sA = smem + NS * WB + (c_g & 1) * AB;
+      const char* sW = smem + buf * WB;
+      const int hr = hx_base + c_kw + rsel, hkey = hr & 7;  // halo-tile row of fragment 0, its swizzle key (fragments are 16 rows apart)
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        const int coff = ((kk * 4 + cq) ^ key) << 4, coffa = ((kk * 4 + cq) ^ hkey) << 4;
+#pragma unroll
+        for (int b = 0; b < FN; b++) wf[kk][b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
+#pragma unroll
+        for (int a = 0; a < FM; a++) af[kk][a] = *(const h8*)(sA + hr * 128 + a * 2048 + coffa);
+      }
+      if (++c_kw == 3) { c_kw = 0; ++c_g; }
+    } else if constexpr (PIN || PP) {
       const char* sA = smem + buf * TILE_BYTES;
       const char* sW = sA + BM * 128;
 #pragma unroll
@@ -420,7 +486,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
         read_frags(cur);
         __builtin_amdgcn_sched_barrier(0);
         const TileSrc t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
-        constexpr int NP = A_PW + W_PW, NM = 2 * FM * FN, GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
+        constexpr int NP = A_PWX + W_PW, NM = 2 * FM * FN, GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
 #pragma unroll
         for (int q = 0; q < NM; q++) {
           const int kk = q / (FM * FN), a = (q / FN) % FM, b = q % FN;
@@ -782,11 +848,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false>
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false, bool HX = false>
 static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
-  constexpr int LDS = NS * (BM + BN) * 128;
-  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP>;
+  constexpr int LDS = HX ? NS * BN * 128 + 2 * (BM / 8 + 1) * 1024 : NS * (BM + BN) * 128;
+  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP, HX>;
   static unsigned long long attr_set = 0;  // per DEVICE: the attribute is stored per device (one bit each)
   if (!((attr_set >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -841,7 +907,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //  11  256x160   3      156 KiB   8 waves, 1 block/CU, two K-tiles of DMA in flight
 //  12  256x160   2      104 KiB   8 waves
 //  13  256x128   3      144 KiB   8 waves
-constexpr int N_GEMM_CFG = 22;
+constexpr int N_GEMM_CFG = 33;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 template <bool CONV>
@@ -860,6 +926,9 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 10: return launch_cfg<2, 2, 2, 4, CONV, 3>(ctx, k, batch);
     case 11: return launch_cfg<4, 2, 4, 5, CONV, 3>(ctx, k, batch);
     case 13: return launch_cfg<4, 2, 4, 4, CONV, 3>(ctx, k, batch);
+    // halo-x variants of 0 and 2 (conv3x3, stride 1: hx_eligible)
+    case 30: if constexpr (CONV) return launch_cfg<2, 2, 4, 5, CONV, 2, false, true>(ctx, k, batch); else break;
+    case 32: if constexpr (CONV) return launch_cfg<2, 2, 4, 4, CONV, 2, false, true>(ctx, k, batch); else break;
 #ifdef TSD_GEMM_EXPERIMENTAL  // measured, not faster: built only to reproduce those numbers
     case 12: return launch_cfg<4, 2, 4, 5, CONV, 2>(ctx, k, batch);
     case 14: return launch_cfg<2, 2, 8, 5, CONV, 3>(ctx, k, batch);
@@ -871,8 +940,26 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 20: return launch_cfg<2, 2, 2, 5, CONV, 5>(ctx, k, batch);  // 64x160, 5-slot ring: slower than 4 slots (667 vs 821 TF)
     case 21: return launch_cfg<2, 2, 2, 4, CONV, 6>(ctx, k, batch);  // 64x128, 6-slot ring
 #endif
-    default: TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
+    default: break;
   }
+  TSD_FAIL(TSD_E_ARG, "gemm: unknown tile configuration %d", id);
+}
+
+// conv3x3 problems the halo-x K order can run: stride 1 on the source grid, whole 128-pixel tiles made of 64- or 128-pixel
+// image-row segments, no split-K
+// OFF by default: the halo-x order sums K in a different order than every other tile configuration, and which
+// configuration runs depends on M - a sample computed alone would no longer equal its row of a batch bit for bit.  Measured
+// with it on (TSD_CONV_HALO=1: the 128x128-tile convs, 2: the 128x160 ones too): decoder 26.1 -> 25.7 ms, encoder 13.95 ->
+// 13.70 ms, UNet step unchanged.  tests/test_gpu_ops.py keeps the path correct against the plain configurations.
+static int hx_mode() {
+  static const int on = getenv("TSD_CONV_HALO") ? atoi(getenv("TSD_CONV_HALO")) : 0;
+  return on;
+}
+static bool hx_shape_ok(const GemmK& k);
+static bool hx_eligible(const GemmK& k) { return hx_mode() > 0 && hx_shape_ok(k); }
+static bool hx_shape_ok(const GemmK& k) {
+  return k.stride == 1 && !k.ups && k.pad == 1 && k.splitk <= 1 && k.Hs == k.Ho && k.Ws == k.Wo && k.Cin % 64 == 0 &&
+         (k.Wo == 64 || k.Wo % 128 == 0) && ((long long)k.Ho * k.Wo) % 128 == 0 && k.M % 128 == 0 && k.Ho < 2040 && k.Wo < 2040;
 }
 
 // Split-K by 2 pays when a 128-row tiling leaves about half the CUs idle and K is long: the M = 2048 level of the UNet
@@ -987,7 +1074,10 @@ int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sa
 
 template <bool CONV>
 static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
-  const int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? k.sk_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV));
+  int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? k.sk_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV));
+  // halo-x measured: -3...5 % on the 128x128-tile convs of the VAE (N = 128 / 256 / 512), nothing on the 128x160 ones (TSD_CONV_HALO=2 turns those on too)
+  if (CONV && g_force_cfg < 0 && hx_eligible(k) && (id == 2 || (id == 0 && hx_mode() >= 2))) id += 30;
+  if ((id == 30 || id == 32) && !(CONV && hx_shape_ok(k))) TSD_FAIL(TSD_E_ARG, "gemm: halo-x tile configuration %d on an ineligible problem", id);
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
 

@@ -138,3 +138,18 @@ def test_attention_64_queries_per_wave_is_bitwise_the_128_query_workgroup(gpu_ct
             assert_close(y2, np.asarray(c.oracle(i), dtype=np.float32), c.tol, c.tol_max, what=name + " (QB=2)")
     finally:
         L.tsd_debug_set_attn_qb(prev)
+
+
+@pytest.mark.parametrize("B,H,Cin,N,cfg,ref", [(2, 64, 64, 160, 30, 0), (2, 64, 640, 320, 30, 0), (1, 128, 128, 128, 32, 2),
+                                               (1, 256, 128, 128, 32, 2), (2, 64, 128, 256, 32, 2)])
+def test_halo_x_conv_order_matches_plain_tiles(gpu_ctx, B, H, Cin, N, cfg, ref):
+    """The opt-in halo-x conv K order (kernels_gemm.hip HX, TSD_CONV_HALO: one staged tile per (kh, channel chunk) serves
+    the three kw taps) against the plain tile configuration on the same synthetic problem: equal up to the fp32 summation
+    order (bit-identical when there is a single channel chunk)."""
+    import ctypes as C
+    from tsd._lib import lib
+    d, r = C.c_float(), C.c_float()
+    assert lib().tsd_debug_gemm_check(gpu_ctx.h, 1, B, H, H, Cin, N, 1, 0, cfg, ref, C.byref(d), C.byref(r)) == 0
+    assert r.value > 0.5 and d.value <= (0.0 if Cin == 64 else 2e-3 * r.value), (d.value, r.value)
+    # an ineligible problem (stride 2) must be refused, not mis-addressed
+    assert lib().tsd_debug_gemm_check(gpu_ctx.h, 1, B, H, H, Cin, N, 2, 0, cfg, ref, C.byref(d), C.byref(r)) != 0
