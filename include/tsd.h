@@ -295,7 +295,9 @@ int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int 
  * (reset != 0 clears the counter); < 0 on error.  Synchronises the context's stream. */
 int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset);
 /* Query blocks per wave of the d = 40 attention core: 0 = chosen by shape (default), 1 = 32 queries per wave, 2 = 64.
- * Both compute every row with the same instruction sequence (bitwise equal results).  Returns the previous mode. */
+ * Both compute every row with the same instruction sequence: bitwise equal results as long as no workgroup takes the exact
+ * repeat (there the repeat and the reference moves are decided per workgroup / per wave, i.e. over different row sets).  The
+ * default choice depends on the layer shape only, never on the batch.  Returns the previous mode. */
 int tsd_debug_set_attn_qb(int mode);
 /* What this board sustains on the matrix pipe: a register-resident dense fp16 MFMA loop (no LDS, no memory) run for about
  * `ms_target` ms at 4 waves per SIMD; reports the achieved TFLOP/s and the shader clock (GHz) during the run.  The nominal

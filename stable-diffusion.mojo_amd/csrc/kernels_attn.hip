@@ -449,7 +449,10 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
       // 64 queries per wave when that still fills the chip (2 workgroups per CU resident) and the key loop is long enough
       // to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (shader clock 1.21 -> 1.46 GHz: the call is power-bound and
       // half the LDS reads is what buys the clock); 77-key cross attention is better off with the 128-query workgroup
-      if (g_attn_qb_force ? g_attn_qb_force == 2 : (g_attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.B * a.H >= 512))
+      // The choice keys on the layer (Sq, Sk, H), never on the batch: the two variants are bitwise equal only while no
+      // workgroup repeats exactly (the repeat is decided per 128- / 256-query workgroup and moves the reference per 32 / 64
+      // rows), so a sample computed alone must run the same variant as its row of a batch (bitwise batch invariance).
+      if (g_attn_qb_force ? g_attn_qb_force == 2 : (g_attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.H >= 64))
         return launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq);
       return launch_fa<40, 1>(ctx, k, a.B, a.H, a.Sq);
     case 80: return launch_fa<80, 1>(ctx, k, a.B, a.H, a.Sq);

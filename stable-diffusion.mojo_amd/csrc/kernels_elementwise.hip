@@ -380,12 +380,12 @@ int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, con
   ProfScope prof(ctx, KC_SMALL_LINEAR, B, N, K, 1);
   const size_t lds = (size_t)B * K * sizeof(float);
   if (lds > 160 * 1024) TSD_FAIL(TSD_E_SHAPE, "small_linear: B*K too large for LDS");
-  static bool attr_set[5] = {false, false, false, false, false};
+  static unsigned long long attr_set[5] = {0, 0, 0, 0, 0};  // per DEVICE: the attribute is stored per device (one bit each)
   const int slot = B <= 1 ? 0 : B <= 2 ? 1 : B <= 4 ? 2 : B <= 8 ? 3 : 4;
   auto launch = [&](auto fn) -> int {
-    if (!attr_set[slot]) {
+    if (!((attr_set[slot] >> (ctx->device & 63)) & 1)) {
       HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set[slot] = true;
+      attr_set[slot] |= 1ull << (ctx->device & 63);
     }
     hipLaunchKernelGGL(fn, dim3(ceil_div(N, 16)), dim3(256), lds, ctx->stream, x, B, K, ldx, w, ldw, bias, N, silu_in, y, ldy);
     return TSD_OK;

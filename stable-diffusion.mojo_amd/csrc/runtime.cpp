@@ -70,15 +70,21 @@ extern "C" int tsd_ctx_destroy(tsd_ctx* c) {
 int ctx_check_splitk(tsd_ctx* c) {
   if (!c->sk_flags) return TSD_OK;
   int n = 0;
+  HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpy(&n, c->sk_flags + 4095, sizeof(int), hipMemcpyDeviceToHost));
-  if (n != 0)
+  if (n != 0) {
+    // reported once, then cleared: the caller re-runs what it computed since the last clean synchronisation point
+    const int zero = 0;
+    (void)hipMemcpy(c->sk_flags + 4095, &zero, sizeof(int), hipMemcpyHostToDevice);
     TSD_FAIL(TSD_E_STATE, "%d split-K hand-off(s) timed out on this context (GPU shared or preempted?): results computed "
-             "since then are invalid; destroy and re-create the context", n);
+             "since the last clean synchronisation are invalid; re-run them", n);
+  }
   return TSD_OK;
 }
 
 extern "C" int tsd_ctx_synchronize(tsd_ctx* c) {
   if (!c) TSD_FAIL(TSD_E_ARG, "tsd_ctx_synchronize: ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ctx_check_splitk(c);
 }

@@ -8,7 +8,7 @@ the encoder's asymmetric pad, 77-token context) plus ragged edge cases (tails in
 import numpy as np
 
 from oracle import models, ops
-from util import TOL_BLOCK, TOL_OP, TOL_OP_MAX, randn, uni
+from util import TOL_BLOCK, TOL_BLOCK_MAX, TOL_OP, TOL_OP_MAX, randn, uni
 
 CASES = {}
 
@@ -303,7 +303,7 @@ class _Mm2(_Mm):
 
 
 # ---- attention ------------------------------------------------------------------------------------------------
-def _sa_case(name, T, D, H, in_bias, ramp=None, tol=5e-3, tol_max=2e-2):
+def _sa_case(name, T, D, H, in_bias, ramp=None, tol=TOL_OP, tol_max=TOL_OP_MAX):
     @case(name, tol=tol, tol_max=tol_max)
     class _S:
         @staticmethod
@@ -335,14 +335,14 @@ _sa_case("self_attention_d40_ragged", 72, 320, 8, False)   # Tq/Tk tails inside 
 _sa_case("self_attention_vae_1head", 64, 128, 1, True)     # VAE style: one head, biases on (unfused path)
 # The fused core keeps a lazily updated softmax reference (kernels_attn.hip, TSD_ATTN_LAZY): these rows make the running maximum
 # climb by 30-45 log2 units across three to six key tiles (and start far below / above zero), so the reference-move path runs.
-_sa_case("self_attention_d40_rising_scores", 320, 320, 8, False, ramp=(0.25, 4.5), tol=2e-2, tol_max=1.5e-1)
-_sa_case("self_attention_d40_falling_scores", 328, 320, 8, False, ramp=(4.5, 0.25), tol=2e-2, tol_max=1.5e-1)
-_sa_case("self_attention_d80_rising_scores", 200, 640, 8, False, ramp=(0.25, 5.0), tol=2e-2, tol_max=1.5e-1)
-_sa_case("self_attention_d160_rising_scores", 136, 1280, 8, False, ramp=(0.25, 6.5), tol=2e-2, tol_max=1.5e-1)
+_sa_case("self_attention_d40_rising_scores", 320, 320, 8, False, ramp=(0.25, 4.5), tol=5e-3, tol_max=1e-2)
+_sa_case("self_attention_d40_falling_scores", 328, 320, 8, False, ramp=(4.5, 0.25), tol=5e-3, tol_max=1e-2)
+_sa_case("self_attention_d80_rising_scores", 200, 640, 8, False, ramp=(0.25, 5.0), tol=5e-3, tol_max=1e-2)
+_sa_case("self_attention_d160_rising_scores", 136, 1280, 8, False, ramp=(0.25, 6.5), tol=5e-3, tol_max=1e-2)
 
 
 def _ca_case(name, Tq, D, H, Tk=77, Dc=768):
-    @case(name, tol=5e-3, tol_max=2e-2)
+    @case(name, tol=TOL_OP, tol_max=TOL_OP_MAX)
     class _Cc:
         @staticmethod
         def build():
@@ -379,7 +379,7 @@ def _res_params(prefix, cin, cout, tag):
 def _unet_res_case(name, cin, cout, H, Cx=None):
     Cx = Cx or cin
 
-    @case(name, tol=TOL_BLOCK, tol_max=3e-2)
+    @case(name, tol=TOL_BLOCK, tol_max=TOL_BLOCK_MAX)
     class _R:
         @staticmethod
         def build():
@@ -422,7 +422,7 @@ def _attn_params(prefix, C, tag, dctx=768):
 def _unet_attn_case(name, nh, ne, H):
     C = nh * ne
 
-    @case(name, tol=TOL_BLOCK, tol_max=3e-2)
+    @case(name, tol=TOL_BLOCK, tol_max=TOL_BLOCK_MAX)
     class _A:
         @staticmethod
         def build():
@@ -455,7 +455,7 @@ _unet_attn_case("unet_attn_8x160", 8, 160, 4)
 
 
 def _vae_res_case(name, cin, cout, H):
-    @case(name, tol=TOL_BLOCK, tol_max=3e-2)
+    @case(name, tol=TOL_BLOCK, tol_max=TOL_BLOCK_MAX)
     class _V:
         @staticmethod
         def build():
@@ -483,7 +483,7 @@ _vae_res_case("vae_res_128_128", 128, 128, 16)
 _vae_res_case("vae_res_256_128", 256, 128, 8)
 
 
-@case("vae_attention_512", tol=TOL_BLOCK, tol_max=3e-2)
+@case("vae_attention_512", tol=TOL_BLOCK, tol_max=TOL_BLOCK_MAX)
 class _VA:
     @staticmethod
     def build():
@@ -505,7 +505,7 @@ class _VA:
         return a.forward(i["x"])
 
 
-@case("time_embedding_mlp", tol=2e-3, tol_max=5e-3)
+@case("time_embedding_mlp", tol=TOL_OP, tol_max=TOL_OP_MAX)
 class _TM:
     @staticmethod
     def build():

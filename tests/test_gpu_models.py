@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import models, ops, rng, sampler, spec
-from util import TOL_MODEL, assert_close, rel_l2
+from util import TOL_MODEL, TOL_MODEL_MAX, assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
 SEED = 1234
@@ -39,7 +39,7 @@ def test_diffusion_forward_matches_oracle(L, diffusion, unet_params):
     temb = np.stack([ops.time_embedding(980.0), ops.time_embedding(20.0)])
     out = diffusion.forward(lat, ctx, temb)
     ref = np.stack([models.diffusion(unet_params, lat[b], ctx[b], temb[b]) for b in range(B)])
-    assert_close(out, ref, TOL_MODEL, None, f"Diffusion.forward L={L}")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, f"Diffusion.forward L={L}")
 
 
 def test_device_rng_equals_host_rng(gpu_ctx, tsd_mod, diffusion, unet_params):
@@ -75,13 +75,36 @@ def test_batch_invariance_is_bitwise_at_odd_sizes(B, L, diffusion):
     np.testing.assert_array_equal(diffusion.forward(lat[B - 1], ctx[B - 1], temb[B - 1]), batched[B - 1])
 
 
+def test_batch_invariance_holds_when_attention_repeats_exactly(gpu_ctx, tsd_mod):
+    """Trained checkpoints have far peakier attention than random weights: with the 64x64-level in_proj scaled x6 (scores x36)
+    many flash-attention workgroups overflow their optimistic softmax pass and repeat exactly.  The kernel variant (32 or 64
+    queries per wave) is chosen from the layer shape only, so a sample computed alone still equals its row of a batch bit for
+    bit on that path too (the choice used to depend on the batch size)."""
+    from tsd._lib import lib
+    P = spec.init_params("diffusion", SEED)
+    for k in ("unet.layer3.layer4.in_proj.weight", "unet.layer21.layer4.in_proj.weight", "unet.layer23.layer4.in_proj.weight"):
+        P[k] = P[k] * 6.0
+    d = tsd_mod.Diffusion(params=P)
+    del P
+    B, L = 3, 64
+    lat, ctx = _inputs(B, L, tag=590)
+    temb = np.stack([ops.time_embedding(t) for t in (900.0, 500.0, 0.0)])
+    lib().tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+    batched = d.forward(lat, ctx, temb)
+    n_exact = lib().tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+    print(f"[parity] peaky attention: {n_exact} of {3 * B * 8 * 16} flash-attention workgroups repeated exactly")
+    assert n_exact > 0 and np.isfinite(batched).all()
+    np.testing.assert_array_equal(d.forward(lat[1], ctx[1], temb[1]), batched[1])
+    d.model.close()
+
+
 def test_context_tail_tokens(diffusion, unet_params):
     """Context lengths that are not a multiple of 8 / 64 (77 in the reference; 5 here) are masked correctly."""
     lat, ctx = _inputs(1, 8, T=5, tag=530)
     temb = ops.time_embedding(300.0)[None]
     out = diffusion.forward(lat, ctx, temb)
     ref = models.diffusion(unet_params, lat[0], ctx[0], temb[0])[None]
-    assert_close(out, ref, TOL_MODEL, None, "Diffusion.forward T=5")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "Diffusion.forward T=5")
 
 
 def test_decoder_forward_matches_oracle(decoder, dec_params):
@@ -89,7 +112,7 @@ def test_decoder_forward_matches_oracle(decoder, dec_params):
     out = decoder.forward(lat)
     ref = np.stack([models.decoder(dec_params, lat[b]) for b in range(2)])
     assert out.shape == (2, 3, 64, 64)
-    assert_close(out, ref, TOL_MODEL, None, "Decoder.forward L=8")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "Decoder.forward L=8")
 
 
 def test_encoder_forward_matches_oracle(gpu_ctx, tsd_mod):
@@ -100,7 +123,7 @@ def test_encoder_forward_matches_oracle(gpu_ctx, tsd_mod):
     out = enc.forward(img, noise)
     ref = models.encoder(P, img[0], noise[0])[None]
     enc.model.close()
-    assert_close(out, ref, TOL_MODEL, None, "Encoder.forward S=64")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "Encoder.forward S=64")
 
 
 def test_session_denoise_matches_oracle(gpu_ctx, tsd_mod, diffusion, unet_params):
@@ -117,7 +140,7 @@ def test_session_denoise_matches_oracle(gpu_ctx, tsd_mod, diffusion, unet_params
     out = s.latents()
     s.close()
     ref = sampler.denoise(unet_params, lat[0], ctx[0], steps, noise[:, 0])[None]
-    assert_close(out, ref, TOL_MODEL, None, "session 3 steps")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "session 3 steps")
 
 
 def test_cfg_batch_equals_two_passes(gpu_ctx, tsd_mod, diffusion):
@@ -212,7 +235,7 @@ def test_per_struct_composition_equals_fused_module(gpu_ctx, tsd_mod, unet_param
     t320 = tsd_mod.get_time_embedding(700.0)
     out = fin.forward(u.forward(lat[0], ctx[0], te.forward(t320)))
     ref = models.diffusion(P, lat[0], ctx[0], ops.time_embedding(700.0))
-    assert_close(out, ref, TOL_MODEL, None, "per-struct UNet composition")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "per-struct UNet composition")
 
 
 # ---- BASELINE.json configs at full size ------------------------------------------------------------------
@@ -233,7 +256,7 @@ def test_config1_256px_10_steps_matches_oracle(gpu_ctx, tsd_mod, diffusion, deco
     got_img = s.images(rescale=True)
     s.close()
     ref_lat = sampler.denoise(unet_params, lat[0], ctx[0], steps, noise[:, 0])[None]
-    assert_close(got_lat, ref_lat, TOL_MODEL, None, "config1: 10-step denoise L=32")
+    assert_close(got_lat, ref_lat, TOL_MODEL, TOL_MODEL_MAX, "config1: 10-step denoise L=32")
     ref_img = ops.rescale_to_u8_range(models.decoder(dec_params, got_lat[0]))[None]  # decode the SAME latents
     assert got_img.shape == (1, 3, 256, 256) and got_img.min() >= 0 and got_img.max() <= 255
     err = float(np.abs(got_img - ref_img).mean())
@@ -256,6 +279,41 @@ def test_headline_size_properties(gpu_ctx, tsd_mod, diffusion):
     # a permutation of the batch permutes the outputs
     perm = np.array([3, 1, 7, 0, 2, 6, 5, 4])
     np.testing.assert_array_equal(diffusion.forward(lat[perm], ctx[perm], temb[perm]), a[perm])
+
+
+def test_headline_size_matches_oracle(gpu_ctx, tsd_mod, diffusion, unet_params):
+    """BASELINE configs[1] size DIRECTLY against the oracle: a batch-8 `Diffusion.forward` at a 64x64 latent - the exact
+    launch set the headline bench times (tile configurations, 2-way split-K at the 16x16 level, 64-query attention waves,
+    the statistics-finalize kernel, two rounds of fused head / tail workgroups) - and two of its samples compared with
+    `oracle.models.diffusion` (diffusion.mojo:309-318).  The oracle needs a few seconds per sample at this size."""
+    B, L = 8, 64
+    lat, ctx = _inputs(B, L, tag=710)
+    ts = (980, 960, 700, 500, 300, 100, 20, 0)
+    temb = np.stack([ops.time_embedding(float(t)) for t in ts])
+    out = diffusion.forward(lat, ctx, temb)
+    for b in (2, 7):
+        ref = models.diffusion(unet_params, lat[b], ctx[b], temb[b])
+        assert_close(out[b], ref, TOL_MODEL, TOL_MODEL_MAX, f"headline size: Diffusion.forward L=64 B=8, sample {b}")
+
+
+def test_decoder_512px_matches_oracle(gpu_ctx, tsd_mod, decoder, dec_params):
+    """One 512x512 decode (latent 64, vae.mojo:221-250) of a batch of 2 against the oracle at full size."""
+    lat = rng.normal(SEED, 720, 2 * 4 * 64 * 64).reshape(2, 4, 64, 64) * 0.18215
+    out = decoder.forward(lat)
+    ref = models.decoder(dec_params, lat[1])
+    assert_close(out[1], ref, TOL_MODEL, TOL_MODEL_MAX, "Decoder.forward 512x512 (L=64)")
+
+
+def test_encoder_512px_matches_oracle(gpu_ctx, tsd_mod):
+    """One 512x512 encode (vae.mojo:131-159) against the oracle at full size."""
+    P = spec.init_params("encoder", SEED, only_used=True)
+    enc = tsd_mod.Encoder(seed=SEED)
+    img = rng.uniform(SEED, 750, 2 * 3 * 512 * 512, 1.0).reshape(2, 3, 512, 512)
+    noise = rng.normal(SEED, 751, 2 * 4 * 64 * 64).reshape(2, 4, 64, 64)
+    out = enc.forward(img, noise)
+    enc.model.close()
+    ref = models.encoder(P, img[1], noise[1])
+    assert_close(out[1], ref, TOL_MODEL, TOL_MODEL_MAX, "Encoder.forward 512x512")
 
 
 def test_decoder_512px_properties(gpu_ctx, tsd_mod, decoder):
@@ -287,7 +345,7 @@ def test_clip_forward_matches_oracle(gpu_ctx, tsd_mod):
     toks[1, :4] = [49406, 1237, 7, 49407]
     out = clip.forward(toks)
     ref = np.stack([models.clip(P, toks[0]), models.clip(P, toks[1])])
-    assert_close(out, ref, TOL_MODEL, None, "CLIP.forward (2 prompts)")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "CLIP.forward (2 prompts)")
     one = clip.forward(toks[1, :4])
     assert one.shape == (77, 768)
     np.testing.assert_array_equal(one, out[1])                  # batch-invariant, zero padding == explicit zeros
@@ -307,7 +365,7 @@ def test_full_size_unet_matches_oracle(gpu_ctx, tsd_mod):
     temb = np.stack([ops.time_embedding(980.0), ops.time_embedding(20.0)])
     out = d.forward(lat, ctx, temb)
     ref = np.stack([models.diffusion_sd15(P, lat[b], ctx[b], temb[b]) for b in range(B)])
-    assert_close(out, ref, TOL_MODEL, None, "full-size Diffusion.forward L=16")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "full-size Diffusion.forward L=16")
     del P
     # headline-size properties (batch 4 at 64x64): finite, bitwise run-to-run, batch-invariant
     lat, ctx = _inputs(4, 64, tag=570)
@@ -319,6 +377,11 @@ def test_full_size_unet_matches_oracle(gpu_ctx, tsd_mod):
     single = d.forward(lat[2], ctx[2], temb[2])
     assert rel_l2(single, a[2]) < 1e-3
     d.model.close()
+    # ... and one sample of that batch-4 call against the oracle at the full 64x64 size (BASELINE configs[4])
+    P = spec.init_params("diffusion_sd15", SEED, only_used=True)
+    ref = models.diffusion_sd15(P, lat[1], ctx[1], temb[1])
+    del P
+    assert_close(a[1], ref, TOL_MODEL, TOL_MODEL_MAX, "full-size Diffusion.forward L=64 B=4, sample 1")
 
 
 def test_torch_norm_unet_and_checkpoint_import(gpu_ctx, tsd_mod):
@@ -332,7 +395,7 @@ def test_torch_norm_unet_and_checkpoint_import(gpu_ctx, tsd_mod):
     temb = np.stack([ops.time_embedding(980.0), ops.time_embedding(20.0)])
     out = d.forward(lat, ctx, temb)
     ref = np.stack([models.diffusion_sd15(P, lat[b], ctx[b], temb[b], tn=True) for b in range(B)])
-    assert_close(out, ref, TOL_MODEL, None, "full-size Diffusion.forward, torch norms, L=16")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "full-size Diffusion.forward, torch norms, L=16")
     plain = np.stack([models.diffusion_sd15(P, lat[b], ctx[b], temb[b]) for b in range(B)])
     assert rel_l2(plain, ref) > 0.05  # the two semantics really differ on these weights
     sd = ck.params_to_diffusers_sd15_unet(P)           # what a checkpoint file would hold (686 tensors)
@@ -353,7 +416,7 @@ def test_vae_torch_variants_and_import(gpu_ctx, tsd_mod):
     P = spec.init_params("decoder_torch", SEED)
     out = dec.forward(lat)
     ref = np.stack([models.decoder(P, lat[b], tn=True) for b in range(2)])
-    assert_close(out, ref, TOL_MODEL, None, "Decoder.forward, torch norms")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "Decoder.forward, torch norms")
     assert rel_l2(np.stack([models.decoder(P, lat[b]) for b in range(2)]), ref) > 0.05
     loaded = ck.load_vae(ck.params_to_diffusers_vae(P, "decoder"), "decoder")
     np.testing.assert_array_equal(loaded.forward(lat), out)
@@ -363,7 +426,7 @@ def test_vae_torch_variants_and_import(gpu_ctx, tsd_mod):
     enc = tsd_mod.Encoder(seed=SEED, variant="encoder_torch")
     Pe = spec.init_params("encoder_torch", SEED)
     oe = enc.forward(img, nz)
-    assert_close(oe, models.encoder(Pe, img, nz, tn=True), TOL_MODEL, None, "Encoder.forward, torch norms")
+    assert_close(oe, models.encoder(Pe, img, nz, tn=True), TOL_MODEL, TOL_MODEL_MAX, "Encoder.forward, torch norms")
     loaded = ck.load_vae(ck.params_to_diffusers_vae(Pe, "encoder"), "encoder")
     np.testing.assert_array_equal(loaded.forward(img, nz), oe)
     loaded.model.close(); enc.model.close()
@@ -385,7 +448,7 @@ def test_clip_torch_variant_matches_transformers(gpu_ctx, tsd_mod, tmp_path):
     tok, ref = z["tokens"], z["reference"]
     clip = ck.load_clip_text(state)
     out = clip.forward(tok)
-    assert_close(out, ref, TOL_MODEL, None, "clip_torch vs transformers.CLIPTextModel")
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "clip_torch vs transformers.CLIPTextModel")
     P = ck.hf_clip_text_to_params(state)
     orc = np.stack([models.clip(P, tok[b], tn=True) for b in range(2)])
     assert rel_l2(orc, ref) < 1e-4

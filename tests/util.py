@@ -23,10 +23,14 @@ def max_rel(y, ref):
 
 
 # Stated tolerances (fp16 storage / fp32 accumulate on the device vs the fp32 oracle), BASELINE.md section 4:
-TOL_OP = 3e-3      # one op: relative L2
-TOL_OP_MAX = 1e-2  # one op: max abs error / max |ref|
-TOL_BLOCK = 1e-2   # residual / attention block
-TOL_MODEL = 5e-2   # full UNet / decoder forward
+# Every bound is <= 4x the largest error measured for its class (profiles/r02_gpu_parity_v5.log, r03_gpu_parity_*.log): ops
+# 3.1e-4 / 7.9e-4, blocks 4.5e-4 / 6.5e-4, whole models 2.7e-3 / 3.1e-3 - a 10x regression of any kernel fails its test.
+TOL_OP = 1.2e-3        # one op: relative L2
+TOL_OP_MAX = 2.5e-3    # one op: max abs error / max |ref|
+TOL_BLOCK = 2e-3       # residual / attention block: relative L2
+TOL_BLOCK_MAX = 3e-3   # residual / attention block: max abs error / max |ref|
+TOL_MODEL = 1e-2       # full UNet / decoder / encoder forward: relative L2
+TOL_MODEL_MAX = 1.2e-2 # full model: max abs error / max |ref|
 
 
 def assert_close(y, ref, tol_l2, tol_max=None, what=""):
