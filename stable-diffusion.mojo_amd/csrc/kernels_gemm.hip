@@ -102,24 +102,35 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // L2 -> CU path three times per channel chunk instead of nine: 71 -> 100 flop per L2 byte for the 128x160 tile, and that
 // path is what bounds these convs.  The W ring keeps its 2 slots; the A tiles live in two buffers of
 // their own (a group's tile must outlive three ring rotations).
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false, bool HX = false>
-__global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * FN <= 20 ? 2 : 1)) void gemm_kernel(const GemmK p) {
+// LW ("loader waves", 0 or 4): LW extra waves per block - one per SIMD - issue every LDS-DMA instruction of the block and do
+// nothing else; the NW compute waves only read fragments and multiply.  An LDS-DMA instruction costs its issuing wave 60-185
+// cycles (MI355X_MICROARCH.md, per-instruction constants), during which that wave issues no MFMA: with one compute wave per SIMD
+// (the one-block-per-CU configurations) the matrix pipe idles for every one of the 4-7 DMA instructions per K tile.  Measured in
+// isolation (scripts/micro/gemm_ws.hip + profiles/r03_micro_gemm_ws.txt): 822 -> 957 TF with loaders, 1137 TF with staggered groups.
+// The loaders run the same ring protocol (counted vmcnt, one barrier per K tile) and end before the epilogue.
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false, bool HX = false, int LW = 0>
+__global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : ((NS <= 2 || WGM * WGN > 4) && FM * FN <= 20 ? 2 : 1)) void gemm_kernel(const GemmK p) {
   constexpr int NW = WGM * WGN;
+  constexpr int NI = LW ? LW : NW;  // waves that issue DMA
+  static_assert(LW == 0 || (LW == 4 && !PP && !HX), "loader waves: one per SIMD, plain ring schedules only");
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int BMw = FM * 16, BNw = FN * 16;
   constexpr int A_INSTR = BM / 8, W_INSTR = BN / 8;  // 1-KiB wave-instructions per tile
-  constexpr int A_PW = (A_INSTR + NW - 1) / NW, W_PW = (W_INSTR + NW - 1) / NW;
+  constexpr int A_PW = (A_INSTR + NI - 1) / NI, W_PW = (W_INSTR + NI - 1) / NI;
   constexpr int TILE_BYTES = (BM + BN) * 128;
   static_assert(!HX || (CONV && NS == 2 && !PP && NW == 4 && BM == 128 && BMw == 64), "halo-x: 128-row conv tiles, 2x2 waves, 2-slot ring");
   constexpr int WB = BN * 128;                              // HX: bytes of a ring slot (W tile only)
   constexpr int AH_INSTR = BM / 8 + 1, AB = AH_INSTR * 1024;  // HX: halo tile = BM + 2*nr rows (<= BM + 8), two buffers after the ring
-  constexpr int A_PWX = HX ? (AH_INSTR + NW - 1) / NW : A_PW;  // A DMA instructions per wave and staged tile
+  constexpr int A_PWX = HX ? (AH_INSTR + NI - 1) / NI : A_PW;  // A DMA instructions per wave and staged tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   TS_MARK(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
+  const bool loader = LW && wave >= NW;      // wave-uniform
+  const bool issuer = LW ? loader : true;    // this wave owns DMA pieces
+  const int iw = LW ? wave - NW : wave;      // its index among the issuing waves
 
   // XCD-aware bijective remap (block b runs on XCD b%8; give each XCD a contiguous tile range).
   // The 8 XCDs form an (8/xcd_n) x xcd_n grid over the tile space: an XCD owns a contiguous block of tile rows AND of
@@ -168,9 +179,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   unsigned a_pk[A_PWX];    // conv: (oy*stride-pad+1) | (ox*stride-pad+1) << 11 | b << 22   (b = 1023: row beyond M)
   // HX geometry (wave-uniform): the tile is nr = 128 / seg image-row segments of seg = min(Wo, 128) pixels
   const int hx_seg = HX ? (p.Wo < 128 ? p.Wo : 128) : 1;
+  if (issuer) {
 #pragma unroll
   for (int i = 0; i < A_PWX; i++) {
-    const int row = (wave + i * NW) * 8 + lrow;
+    const int row = (iw + i * NI) * 8 + lrow;
     int m = m0 + row;
     const bool ok = m < p.M;
     if (!ok) m = p.M - 1;
@@ -196,14 +208,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       a_off1[i] = PAD_OFF;
     }
   }
+  }
   unsigned w_off[W_PW];
+  if (issuer) {
 #pragma unroll
   for (int i = 0; i < W_PW; i++) {
-    const int rho = (wave + i * NW) * 8 + lrow;  // LDS row of the W tile
+    const int rho = (iw + i * NI) * 8 + lrow;  // LDS row of the W tile
     const int wq = rho / BNw, rr = rho - wq * BNw, fn = rr >> 4, ii = rr & 15;
     int n = n0 + wq * BNw + (ii >> 2) * (4 * FN) + fn * 4 + (ii & 3);  // column permutation
     if (n >= p.N) n = p.N - 1;
     w_off[i] = ((unsigned)n * (unsigned)p.ldw + cch * 8) * 2;
+  }
   }
 
   // conv: running (tap, channel-chunk) of the NEXT tile to stage
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + sy) * p.Ws + sx) * (unsigned)p.lda0 + cch * 8) * 2 : PAD_OFF;
     }
   };
-  if constexpr (CONV) conv_tap_ptrs(st_tap);
+  if constexpr (CONV) { if (issuer) conv_tap_ptrs(st_tap); }
 
   // One K-tile = A_PW + W_PW DMA instructions per wave.  A TileSrc holds the wave-uniform part of their addresses;
   // stage_piece() issues the i-th instruction so the pinned schedule can drop them one at a time into the shadow of
@@ -266,17 +281,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     char* sA = HX ? smem + NS * WB + t.abuf * AB : smem + buf * TILE_BYTES;
     char* sW = HX ? smem + buf * WB : sA + BM * 128;
     if (i < A_PWX) {
-      const int j = wave + i * NW;
+      const int j = iw + i * NI;
       if constexpr (HX) {
         if (t.a_on && j < AH_INSTR) blds16(t.ra, a_off1[i], t.a_soff, sA + j * 1024);
-      } else if (A_INSTR % NW == 0 || j < A_INSTR) {
+      } else if (A_INSTR % NI == 0 || j < A_INSTR) {
         if constexpr (!CONV) blds16(t.ra, t.second ? a_off1[i] : a_off[i], t.a_soff, sA + j * 1024);
         else blds16(t.ra, a_off1[i], t.a_soff, sA + j * 1024);
       }
     } else {
-      const int iw = i - A_PWX;
-      const int j = wave + iw * NW;
-      if (W_INSTR % NW == 0 || j < W_INSTR) blds16(t.rw, w_off[iw], t.w_soff, sW + j * 1024);
+      const int ii = i - A_PWX;
+      const int j = iw + ii * NI;
+      if (W_INSTR % NI == 0 || j < W_INSTR) blds16(t.rw, w_off[ii], t.w_soff, sW + j * 1024);
     }
   };
   auto stage_advance = [&]() {
@@ -381,13 +396,40 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 
   // DMA instructions per stage per wave: waves below the remainder issue one more (wave-uniform)
   constexpr int LPS_HI = A_PW + W_PW;
-  constexpr int LPS_LO = (A_INSTR % NW ? A_PW - 1 : A_PW) + (W_INSTR % NW ? W_PW - 1 : W_PW);
-  static_assert(NS == 2 || A_INSTR % NW == 0, "A tile loads must divide evenly among the waves");
-  const bool lps_hi = (W_INSTR % NW == 0) || wave < (W_INSTR % NW);
+  constexpr int LPS_LO = (A_INSTR % NI ? A_PW - 1 : A_PW) + (W_INSTR % NI ? W_PW - 1 : W_PW);
+  static_assert(NS == 2 || A_INSTR % NI == 0, "A tile loads must divide evenly among the waves");
+  const bool lps_hi = (W_INSTR % NI == 0) || iw < (W_INSTR % NI);
+  if constexpr (LW > 0) {
+    if (loader) {
+      // Loader wave: the block's whole DMA stream, same ring protocol as the compute waves' loops below - before barrier kt
+      // tile kt has landed (counted vmcnt leaves the younger tiles in flight); after it every compute wave has retired its
+      // reads of tile kt-1 (lgkmcnt(0) in front of its barrier), so that slot is refilled with tile kt+NS-1.  No dead tail
+      // DMAs: nothing of this wave is in flight when it leaves, the epilogue's LDS staging starts behind barrier nk-1.
+#pragma unroll
+      for (int s = 0; s < NS - 1; s++)
+        if (s < nk) stage(s, s);
+      int nxt = NS - 1;
+      for (int kt = 0; kt < nk; kt++) {
+        const int ahead = min(NS - 2, nk - 1 - kt);
+        if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
+        else if (NS >= 5 && ahead == 3) { if (lps_hi) wait_vmcnt<3 * LPS_HI>(); else wait_vmcnt<3 * LPS_LO>(); }
+        else if (NS >= 4 && ahead == 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
+        else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      }
+      return;
+    }
+  }
   if constexpr (!PP) {
+    if constexpr (LW == 0) {
   #pragma unroll
     for (int s = 0; s < NS - 1; s++)
       if (s < nk) stage(s, s);
+    }
     int cur = 0, nxt = NS - 1;  // ring slots of tile kt and tile kt+NS-1
     TS_MARK(1);
     // the K loop starts on a 256-byte boundary (padding = s_nop, executed once): +0.45 % on the step, measured
@@ -397,7 +439,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     // the MFMAs of tile kt-1 instead of as a burst right after the barrier (72 ds_read_b128 from the four waves hold the
     // LDS, and every wave's issue, for ~300 cycles per K-tile).  Same products in the same order: results are bitwise
     // identical to the other schedules.
-    constexpr bool PIPE = PIN && (NS >= 3 || FM * FN <= 10) && NW == 4 && (TSD_GEMM_PIPE != 0);
+    // with loader waves the block runs two waves per SIMD (256 registers each): the second fragment set fits only for the 32-row wave tiles
+    constexpr bool PIPE = PIN && (NS >= 3 || FM * FN <= 10) && NW == 4 && (TSD_GEMM_PIPE != 0) && (LW == 0 || FM * FN <= 10);
     if constexpr (PIPE) {
       h8 afA[2][FM], wfA[2][FN], afB[2][FM], wfB[2][FN];
       auto step = [&](int kt, h8 (&naf)[2][FM], h8 (&nwf)[2][FN], const h8 (&paf)[2][FM], const h8 (&pwf)[2][FN],
@@ -405,20 +448,22 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
         const char *sA = smem, *sW = smem;
         TileSrc t;
         if (have_next) {
+          if constexpr (LW == 0) {
           const int ahead = min(NS - 2, nk - 1 - kt);
           if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
           else if (NS >= 5 && ahead == 3) { if (lps_hi) wait_vmcnt<3 * LPS_HI>(); else wait_vmcnt<3 * LPS_LO>(); }
           else if (NS >= 4 && ahead == 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
           else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
           else wait_vmcnt<0>();
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt-1 are done: its slot may be refilled
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           sA = smem + cur * TILE_BYTES;
           sW = sA + BM * 128;
-          t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
+          if constexpr (LW == 0) t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
         }
-        constexpr int NP = A_PW + W_PW, NM = 2 * FM * FN, NR = 2 * (FM + FN), GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
+        constexpr int NP = LW ? 0 : A_PW + W_PW, NM = 2 * FM * FN, NR = 2 * (FM + FN), GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
         auto read_one = [&](int i) {  // fragment i of tile kt: per k-half the FM A fragments, then the FN W fragments
           const int kk = i / (FM + FN), j = i - kk * (FM + FN);
           const int coff = ((kk * 4 + cq) ^ key) << 4;
@@ -450,7 +495,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
           }
         }
         if (have_next) {
-          stage_advance();
+          if constexpr (LW == 0) stage_advance();
           cur = (cur + 1 == NS) ? 0 : cur + 1;
           nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
@@ -470,12 +515,16 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
     } else
     for (int kt = 0; kt < nk; kt++) {
       // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
+      if constexpr (LW == 0) {
       const int ahead = min(NS - 2, nk - 1 - kt);
       if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
       else if (NS >= 5 && ahead == 3) { if (lps_hi) wait_vmcnt<3 * LPS_HI>(); else wait_vmcnt<3 * LPS_LO>(); }
       else if (NS >= 4 && ahead == 2) { if (lps_hi) wait_vmcnt<2 * LPS_HI>(); else wait_vmcnt<2 * LPS_LO>(); }
       else if (NS >= 3 && ahead == 1) { if (lps_hi) wait_vmcnt<LPS_HI>(); else wait_vmcnt<LPS_LO>(); }
       else wait_vmcnt<0>();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile kt-1 retired before the loaders may refill its slot
+      }
       __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; slot of tile kt-1 is free
       asm volatile("" ::: "memory");
       if constexpr (PIN) {
@@ -485,8 +534,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
         // groups behind lgkmcnt(0), exposing 3-4 LDS round trips per K-tile.
         read_frags(cur);
         __builtin_amdgcn_sched_barrier(0);
-        const TileSrc t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
-        constexpr int NP = A_PWX + W_PW, NM = 2 * FM * FN, GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
+        TileSrc t;
+        if constexpr (LW == 0) t = tile_src(kt + NS - 1, kt + NS - 1 < nk);
+        constexpr int NP = LW ? 0 : A_PWX + W_PW, NM = 2 * FM * FN, GAP = NM / (NP + 1) > 0 ? NM / (NP + 1) : 1;
 #pragma unroll
         for (int q = 0; q < NM; q++) {
           const int kk = q / (FM * FN), a = (q / FN) % FM, b = q % FN;
@@ -499,9 +549,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
         }
 #pragma unroll
         for (int i = NM / GAP; i < NP; i++) stage_piece(t, nxt, i);  // more DMA instructions than MFMA gaps (thin tiles)
-        stage_advance();
+        if constexpr (LW == 0) stage_advance();
       } else {
-        if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+        if constexpr (LW == 0) { if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt); }
         compute(cur);
       }
       cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -664,6 +714,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
       for (int pass = 0; pass < FM / 2; pass++) {
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
+          // one 16-row fragment block at a time: left to itself the scheduler hoists the bias / row-vector loads of every
+          // unrolled (pass, hf) iteration to the top of the epilogue and spills (3848 scratch accesses in the 128x160 conv kernel)
+          __builtin_amdgcn_sched_barrier(0);
           const int a = pass * 2 + hf;
           const int m = m0 + wm * BMw + a * 16 + rsel;
           float v[4 * FN];
@@ -676,24 +729,24 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 #pragma unroll
             for (int j = 0; j < 4 * FN; j++) v[j] += bm;
           }
+          // Column terms are loaded branch-free (clamped address, columns beyond N are never stored): a per-lane branch around each
+          // f4 made the compiler carry whole copies of v[] across the divergent regions - 3848 scratch accesses in this kernel
           if (epi & EPI_BIAS_N) {
 #pragma unroll
-            for (int b = 0; b < FN; b++)
-              if (nb + b * 4 < p.N) {
-                const f4 bv = *(const f4*)(p.bias + nb + b * 4);
+            for (int b = 0; b < FN; b++) {
+              const f4 bv = *(const f4*)(p.bias + min(nb + b * 4, p.N - 4));
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
-              }
+              for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+            }
           }
           if (epi & EPI_ROWVEC) {
             const float* rv = p.rowvec + (long long)((m < p.M ? m : p.M - 1) / p.rows_per_batch) * p.rowvec_ld;
 #pragma unroll
-            for (int b = 0; b < FN; b++)
-              if (nb + b * 4 < p.N) {
-                const f4 bv = *(const f4*)(rv + nb + b * 4);
+            for (int b = 0; b < FN; b++) {
+              const f4 bv = *(const f4*)(rv + min(nb + b * 4, p.N - 4));
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
-              }
+              for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+            }
           }
           float* row = ep + (hf * 16 + rsel) * EPP + g * (4 * FN);
 #pragma unroll
@@ -702,6 +755,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
         // same-wave LDS operations complete in order: the row-major reads below see the stores above
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
+          __builtin_amdgcn_sched_barrier(0);
           const int t = lane + 64 * i;
           const int r = t / CH, c = t - r * CH;
           const int m = m0 + wm * BMw + pass * 32 + r;
@@ -771,6 +825,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
   }
 #pragma unroll
   for (int a = 0; a < FM; a++) {
+    __builtin_amdgcn_sched_barrier(0);  // one fragment row at a time (this rarely taken path must not set the kernel's scratch size)
     const int m = m0 + wm * BMw + a * 16 + rsel;
     if (m >= p.M) continue;
     float v[4 * FN];
@@ -783,24 +838,23 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 #pragma unroll
       for (int j = 0; j < 4 * FN; j++) v[j] += bm;
     }
+    // column terms branch-free (clamped address; columns beyond N are never stored) - see the coalesced path
     if (epi & EPI_BIAS_N) {
 #pragma unroll
-      for (int b = 0; b < FN; b++)
-        if (nb + b * 4 < p.N) {
-          const f4 bv = *(const f4*)(p.bias + nb + b * 4);
+      for (int b = 0; b < FN; b++) {
+        const f4 bv = *(const f4*)(p.bias + min(nb + b * 4, p.N - 4));
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
-        }
+        for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+      }
     }
     if (epi & EPI_ROWVEC) {
       const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.rowvec_ld;
 #pragma unroll
-      for (int b = 0; b < FN; b++)
-        if (nb + b * 4 < p.N) {
-          const f4 bv = *(const f4*)(rv + nb + b * 4);
+      for (int b = 0; b < FN; b++) {
+        const f4 bv = *(const f4*)(rv + min(nb + b * 4, p.N - 4));
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
-        }
+        for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
+      }
     }
     if (epi & EPI_RESIDUAL) {
       long long rrow = m;
@@ -809,14 +863,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
         const int bb = m / hw, rem = m - bb * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
         rrow = ((long long)bb * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
       }
-      const half_t* rp = p.R + (long long)bz * p.sR + rrow * p.ldr + nb;
+      const half_t* rp = p.R + (long long)bz * p.sR + rrow * p.ldr;
 #pragma unroll
-      for (int b = 0; b < FN; b++)
-        if (nb + b * 4 < p.N) {
-          const h4 rvv = *(const h4*)(rp + b * 4);
+      for (int b = 0; b < FN; b++) {
+        const h4 rvv = *(const h4*)(rp + min(nb + b * 4, p.N - 4));
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[b * 4 + r] += (float)rvv[r];
-        }
+        for (int r = 0; r < 4; r++) v[b * 4 + r] += (float)rvv[r];
+      }
     }
     if (epi & EPI_GEGLU) {
       half_t* cp = (half_t*)p.C + (long long)bz * p.sC + (long long)m * p.ldc + (nb >> 1);
@@ -848,19 +901,19 @@ __global__ __launch_bounds__(WGM* WGN * 64, ((NS <= 2 || WGM * WGN > 4) && FM * 
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false, bool HX = false>
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false, bool HX = false, int LW = 0>
 static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int LDS = HX ? NS * BN * 128 + 2 * (BM / 8 + 1) * 1024 : NS * (BM + BN) * 128;
-  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP, HX>;
+  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP, HX, LW>;
   static unsigned long long attr_set = 0;  // per DEVICE: the attribute is stored per device (one bit each)
   if (!((attr_set >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set |= 1ull << (ctx->device & 63);
     if (getenv("TSD_DEBUG_OCC")) {
       int nb = -1;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, WGM * WGN * 64, LDS);
-      fprintf(stderr, "[occ] gemm<%d,%d,%d,%d,%d,%d> LDS=%d blocks/CU=%d (%s)\n", WGM, WGN, FM, FN, (int)CONV, NS, LDS, nb,
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, (WGM * WGN + LW) * 64, LDS);
+      fprintf(stderr, "[occ] gemm<%d,%d,%d,%d,%d,%d,lw%d> LDS=%d blocks/CU=%d (%s)\n", WGM, WGN, FM, FN, (int)CONV, NS, LW, LDS, nb,
               hipGetErrorString(e));
     }
   }
@@ -886,7 +939,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
     kk.xcd_n = best;
   }
   dim3 grid(tiles_m * kk.tiles_n * (kk.splitk > 1 ? kk.splitk : 1), batch);
-  hipLaunchKernelGGL(fn, grid, dim3(WGM * WGN * 64), LDS, ctx->stream, kk);
+  hipLaunchKernelGGL(fn, grid, dim3((WGM * WGN + LW) * 64), LDS, ctx->stream, kk);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -907,7 +960,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //  11  256x160   3      156 KiB   8 waves, 1 block/CU, two K-tiles of DMA in flight
 //  12  256x160   2      104 KiB   8 waves
 //  13  256x128   3      144 KiB   8 waves
-constexpr int N_GEMM_CFG = 33;
+constexpr int N_GEMM_CFG = 54;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 template <bool CONV>
@@ -926,6 +979,15 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 10: return launch_cfg<2, 2, 2, 4, CONV, 3>(ctx, k, batch);
     case 11: return launch_cfg<4, 2, 4, 5, CONV, 3>(ctx, k, batch);
     case 13: return launch_cfg<4, 2, 4, 4, CONV, 3>(ctx, k, batch);
+    // loader-wave variants (LW = 4): 40 + the id of the 4-wave one-block-per-CU configuration they extend, 51 = cfg 11 + loaders
+    case 45: return launch_cfg<2, 2, 4, 5, CONV, 3, false, false, 4>(ctx, k, batch);
+    case 46: return launch_cfg<2, 2, 2, 5, CONV, 4, false, false, 4>(ctx, k, batch);
+    case 47: return launch_cfg<2, 2, 2, 5, CONV, 3, false, false, 4>(ctx, k, batch);
+    case 48: return launch_cfg<2, 2, 4, 4, CONV, 3, false, false, 4>(ctx, k, batch);
+    case 49: return launch_cfg<2, 2, 2, 4, CONV, 4, false, false, 4>(ctx, k, batch);
+    case 50: return launch_cfg<2, 2, 2, 4, CONV, 3, false, false, 4>(ctx, k, batch);
+    case 51: return launch_cfg<4, 2, 4, 5, CONV, 3, false, false, 4>(ctx, k, batch);
+    case 53: return launch_cfg<4, 2, 4, 4, CONV, 3, false, false, 4>(ctx, k, batch);
     // halo-x variants of 0 and 2 (conv3x3, stride 1: hx_eligible)
     case 30: if constexpr (CONV) return launch_cfg<2, 2, 4, 5, CONV, 2, false, true>(ctx, k, batch); else break;
     case 32: if constexpr (CONV) return launch_cfg<2, 2, 4, 4, CONV, 2, false, true>(ctx, k, batch); else break;
@@ -1054,10 +1116,10 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
 // rows / columns of one wave's output sub-tile for tile configuration `id` (FM*16, FN*16)
 static void cfg_wave_tile(int id, int* bmw, int* bnw) {
   switch (id) {
-    case 0: case 5: case 11: *bmw = 64; *bnw = 80; break;
-    case 1: case 6: case 7: *bmw = 32; *bnw = 80; break;
-    case 2: case 8: case 13: *bmw = 64; *bnw = 64; break;
-    case 3: case 9: case 10: *bmw = 32; *bnw = 64; break;
+    case 0: case 5: case 11: case 45: case 51: *bmw = 64; *bnw = 80; break;
+    case 1: case 6: case 7: case 46: case 47: *bmw = 32; *bnw = 80; break;
+    case 2: case 8: case 13: case 48: case 53: *bmw = 64; *bnw = 64; break;
+    case 3: case 9: case 10: case 49: case 50: *bmw = 32; *bnw = 64; break;
     default: *bmw = 0; *bnw = 0; break;  // thin / experimental tiles: no epilogue statistics
   }
 }
