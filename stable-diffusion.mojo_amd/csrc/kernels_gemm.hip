@@ -409,6 +409,36 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       for (int s = 0; s < NS - 1; s++)
         if (s < nk) stage(s, s);
       int nxt = NS - 1;
+      if constexpr (NW == 8) {
+        // staggered schedule (see the compute side below): four barriers per K tile, aligned with compute group 0; the wave's
+        // pieces of tile kt+2 are spread over the four intervals, tile kt+1 has landed before the fourth barrier
+        static_assert(NW != 8 || NS == 3, "staggered schedule: 3-slot ring");
+        if (nk > 1) wait_vmcnt<LPS_HI>(); else wait_vmcnt<0>();  // tile 0 has landed (LPS_HI == LPS_LO: pieces divide evenly over 4 loaders)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int NP = A_PW + W_PW;
+        static_assert(NW != 8 || LPS_HI == LPS_LO, "loader pieces must divide evenly");
+        for (int kt = 0; kt < nk; kt++) {
+          const bool live = kt + 2 < nk;
+          TileSrc t;
+          if (live) t = tile_src(kt + 2, true);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (live) {
+#pragma unroll
+              for (int i = q * NP / 4; i < (q + 1) * NP / 4; i++) stage_piece(t, nxt, i);
+            }
+            if (q == 3) {
+              if (live) { stage_advance(); wait_vmcnt<NP>(); } else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+          }
+          nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+        __builtin_amdgcn_s_barrier();  // group 1's last phase
+        return;
+      }
       for (int kt = 0; kt < nk; kt++) {
         const int ahead = min(NS - 2, nk - 1 - kt);
         if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
@@ -424,7 +454,47 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       return;
     }
   }
-  if constexpr (!PP) {
+  if constexpr (LW > 0 && NW == 8) {
+    // Staggered, wave-specialised schedule (scripts/micro/gemm_ws.hip: 1.14 PF where the lockstep loop reaches 0.82-0.89): the
+    // eight compute waves form two groups that run one barrier apart, so on every SIMD one wave multiplies a 32-deep k-step
+    // (FM x FN MFMAs from 9 fragment registers) while its partner reads the next k-step's fragments; the four loader waves
+    // issue all DMA.  Same products in the same order as every other configuration: bitwise-identical results.
+    const bool grp1 = wave >= NW / 2;
+    __builtin_amdgcn_s_barrier();  // tile 0 has landed (loaders)
+    asm volatile("" ::: "memory");
+    if (grp1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt++) {
+      const char* sA = smem + cur * TILE_BYTES;
+      const char* sW = sA + BM * 128;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        const int coff = ((kk * 4 + cq) ^ key) << 4;
+        h8 afk[FM], wfk[FN];
+#pragma unroll
+        for (int b = 0; b < FN; b++) wfk[b] = *(const h8*)(sW + w_rd + b * 2048 + coff);
+#pragma unroll
+        for (int a = 0; a < FM; a++) afk[a] = *(const h8*)(sA + a_rd + a * 2048 + coff);
+        __builtin_amdgcn_sched_barrier(0);
+        // the tile's last reads retire BEFORE the barrier: the loaders refill its slot right after it
+        if (kk == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < FM; a++)
+#pragma unroll
+          for (int b = 0; b < FN; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfk[b], afk[a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+    }
+    if (!grp1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+  } else if constexpr (!PP) {
     if constexpr (LW == 0) {
   #pragma unroll
     for (int s = 0; s < NS - 1; s++)
@@ -1105,7 +1175,15 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   //  * fewer tiles than that: 64-row tiles with 3 ring slots, 4 when K is long.
   const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
   const long long t256 = (long long)ceil_div(M, 256) * ceil_div(N, BN) * batch;
-  static const int tune = getenv("TSD_GEMM_TUNE") ? atoi(getenv("TSD_GEMM_TUNE")) : 3;  // A/B switch for the two rules below
+  static const int tune = getenv("TSD_GEMM_TUNE") ? atoi(getenv("TSD_GEMM_TUNE")) : 7;  // A/B switch for the two rules below
+  // Round 3: the staggered wave-specialised 256-row tiles (51 / 53: 8 compute waves in two groups + 4 loader waves) where a
+  // 256-row tiling gives every CU whole tiles - measured -5...-10 % against configurations 0 / 2 / 11 on these shapes
+  // (profiles/r03_loader_waves_ab.txt); TSD_GEMM_TUNE bit 2 turns them off.  Results are bitwise those of every other tile.
+  if ((tune & 4) && M % 256 == 0) {
+    if (n160 && conv && t256 >= 256 && t256 % 256 == 0) return 51;
+    if (n160 && !conv && (t256 == 256 || t256 == 512)) return 51;
+    if (!n160 && conv && N % 128 == 0 && N >= 256 && t256 >= 512) return 53;
+  }
   if ((tune & 1) && !conv && n160 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
   if (t128 >= 512) return n160 ? 0 : 2;
   if (t128 >= 192) return (K >= 2560 || !(tune & 2)) ? (n160 ? 5 : 8) : (n160 ? 1 : 3);
