@@ -299,6 +299,10 @@ int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset);
  * repeat (there the repeat and the reference moves are decided per workgroup / per wave, i.e. over different row sets).  The
  * default choice depends on the layer shape only, never on the batch.  Returns the previous mode. */
 int tsd_debug_set_attn_qb(int mode);
+/* Self-attention (Sq == Sk): the optimistic softmax reference is max(row maximum of key tile 0, row maximum over the query's
+ * own 32-key block) + headroom; on = 0 restores the tile-0-only reference (to measure what the second reference saves on
+ * peaked score distributions).  Returns the previous setting. */
+int tsd_debug_set_attn_diag(int on);
 /* What this board sustains on the matrix pipe: a register-resident dense fp16 MFMA loop (no LDS, no memory) run for about
  * `ms_target` ms at 4 waves per SIMD; reports the achieved TFLOP/s and the shader clock (GHz) during the run.  The nominal
  * dense peak assumes the boost clock; under matrix-pipe load the board's power limit sets the clock. */

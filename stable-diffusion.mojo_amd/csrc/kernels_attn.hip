@@ -45,6 +45,7 @@ struct AttnK {
   int ldq, ldk, ldvt, ldo;
   int H, Sq, Sk, Skv;  // Skv: number of valid V^T columns (Sk rounded up to 8)
   float c;             // scale * log2(e)
+  int diag;            // self-attention (Sq == Sk): the optimistic reference also covers each query's own 32-key block
 };
 
 __device__ __forceinline__ void glds16a(const void* g, void* l) {
@@ -126,6 +127,37 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
       // and the per-score v_fma_f32 of the softmax disappears
 #pragma unroll
       for (int e = 0; e < 8; e++) qf[qb][ks][e] = (half_t)((float)qf[qb][ks][e] * p.c);
+    }
+  }
+
+  // ---- second optimistic reference (round 3): the query's OWN 32-key block ------------------------------------
+  // Trained self-attention is peaked on a token's own neighbourhood; when that is not in key tile 0 a score can exceed tile 0's
+  // row maximum by more than the 20 log2 units the optimistic pass tolerates and the whole workgroup repeats exactly (a 2x
+  // cliff on this kernel).  One extra S^T block per query block (3 MFMAs, K fragments straight from global memory, once per
+  // kernel) gives the row maximum over keys q0+32*qb .. +31 as a second lower bound of the true maximum.  The key set is the
+  // same for the 32- and the 64-query-per-wave variants, so they stay bitwise equal.
+  float mxd[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; qb++) {
+    mxd[qb] = -1.0e30f;
+    if (p.diag) {
+      int krow = q0 + qb * 32 + l31;
+      if (krow >= p.Sk) krow = p.Sk - 1;
+      const half_t* kp = Kb + (long long)krow * p.ldk;
+      f16v sd;
+#pragma unroll
+      for (int r = 0; r < 16; r++) sd[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        const int ch = ks * 2 + hi;
+        h8 kf = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ch < DCH) kf = *(const h8*)(kp + ch * 8);
+        sd = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], sd, 0, 0, 0);
+      }
+      float m = sd[0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) m = fmaxf(m, sd[r]);
+      mxd[qb] = fmaxf(m, __shfl_xor(m, 32));
     }
   }
 
@@ -261,7 +293,7 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
       if (__any(move)) {  // wave-uniform: move the reference (always on tile 0, then rarely)
 #pragma unroll
         for (int qb = 0; qb < QB; qb++) {
-          const float delta = t == 0 ? mx[qb] + (EXACT ? 0.f : TSD_ATTN_HEADROOM) : fmaxf(mx[qb], 0.f);
+          const float delta = t == 0 ? (EXACT ? mx[qb] : fmaxf(mx[qb], mxd[qb]) + TSD_ATTN_HEADROOM) : fmaxf(mx[qb], 0.f);
           const float alpha = __builtin_amdgcn_exp2f(-delta);
           m_run[qb] += delta;
 #pragma unroll
@@ -408,6 +440,12 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
 static int g_attn_qb = 2;     // d = 40: 32-query blocks per wave (TSD_ATTN_QB=1 selects the 128-query workgroup)
 static int g_attn_qb_force = 0;  // tsd_debug_set_attn_qb: 0 = by shape, 1 / 2 = that many query blocks per wave whenever d = 40
+static int g_attn_diag = 1;  // tsd_debug_set_attn_diag: 0 = optimistic reference from key tile 0 only (the round-2 behaviour)
+extern "C" int tsd_debug_set_attn_diag(int on) {
+  const int prev = g_attn_diag;
+  if (on == 0 || on == 1) g_attn_diag = on;
+  return prev;
+}
 extern "C" int tsd_debug_set_attn_qb(int mode) {
   const int prev = g_attn_qb_force;
   if (mode >= 0 && mode <= 2) g_attn_qb_force = mode;
@@ -444,6 +482,7 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   k.ldq = a.ldq; k.ldk = a.ldk; k.ldvt = a.ldvt; k.ldo = a.ldo;
   k.H = a.H; k.Sq = a.Sq; k.Sk = a.Sk; k.Skv = std::min(round_up(a.Sk, 8), a.ldvt);
   k.c = a.scale * 1.4426950408889634f;
+  k.diag = (g_attn_diag && a.Sq == a.Sk) ? 1 : 0;
   switch (a.d) {
     case 40:
       // 64 queries per wave when that still fills the chip (2 workgroups per CU resident) and the key loop is long enough

@@ -1030,7 +1030,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //  11  256x160   3      156 KiB   8 waves, 1 block/CU, two K-tiles of DMA in flight
 //  12  256x160   2      104 KiB   8 waves
 //  13  256x128   3      144 KiB   8 waves
-constexpr int N_GEMM_CFG = 54;
+constexpr int N_GEMM_CFG = 56;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 template <bool CONV>
@@ -1058,6 +1058,8 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 50: return launch_cfg<2, 2, 2, 4, CONV, 3, false, false, 4>(ctx, k, batch);
     case 51: return launch_cfg<4, 2, 4, 5, CONV, 3, false, false, 4>(ctx, k, batch);
     case 53: return launch_cfg<4, 2, 4, 4, CONV, 3, false, false, 4>(ctx, k, batch);
+    case 54: return launch_cfg<4, 2, 2, 5, CONV, 3, false, false, 4>(ctx, k, batch);  // 128x160, staggered: 8 compute waves of 32x80
+    case 55: return launch_cfg<4, 2, 2, 4, CONV, 3, false, false, 4>(ctx, k, batch);  // 128x128
     // halo-x variants of 0 and 2 (conv3x3, stride 1: hx_eligible)
     case 30: if constexpr (CONV) return launch_cfg<2, 2, 4, 5, CONV, 2, false, true>(ctx, k, batch); else break;
     case 32: if constexpr (CONV) return launch_cfg<2, 2, 4, 4, CONV, 2, false, true>(ctx, k, batch); else break;
@@ -1195,9 +1197,9 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
 static void cfg_wave_tile(int id, int* bmw, int* bnw) {
   switch (id) {
     case 0: case 5: case 11: case 45: case 51: *bmw = 64; *bnw = 80; break;
-    case 1: case 6: case 7: case 46: case 47: *bmw = 32; *bnw = 80; break;
+    case 1: case 6: case 7: case 46: case 47: case 54: *bmw = 32; *bnw = 80; break;
     case 2: case 8: case 13: case 48: case 53: *bmw = 64; *bnw = 64; break;
-    case 3: case 9: case 10: case 49: case 50: *bmw = 32; *bnw = 64; break;
+    case 3: case 9: case 10: case 49: case 50: case 55: *bmw = 32; *bnw = 64; break;
     default: *bmw = 0; *bnw = 0; break;  // thin / experimental tiles: no epilogue statistics
   }
 }

@@ -328,6 +328,31 @@ def _sa_case(name, T, D, H, in_bias, ramp=None, tol=TOL_OP, tol_max=TOL_OP_MAX):
     return _S
 
 
+def _sa_self_peaked_case(name, T, D, H, gain):
+    """Self-attention whose key projection equals its query projection: every token's largest score is with ITSELF (|q_i|^2 /
+    sqrt(d), ~25 nats above an average score at this gain) - the peaked-on-the-own-neighbourhood pattern of trained SD
+    self-attention.  For queries beyond key tile 0 that score is > 20 log2 units above tile 0's row maximum."""
+    @case(name, tol=TOL_OP, tol_max=TOL_OP_MAX)
+    class _S:
+        @staticmethod
+        def build():
+            wq = _w(31, D, D) * gain
+            wi = np.concatenate([wq, wq, _w(32, D, D)], axis=0)
+            return dict(x=randn(33, T, D), wi=wi, wo=_w(34, D, D), bo=randn(35, D) * 0.1)
+
+        @staticmethod
+        def oracle(i):
+            return ops.self_attention(i["x"], H, i["wi"], None, i["wo"], i["bo"])
+
+        @staticmethod
+        def device(tsd, i):
+            a = tsd.Self_Attention(H, D, in_bias=False)
+            a.in_proj.weight, a.out_proj.weight, a.out_proj.bias = i["wi"], i["wo"], i["bo"]
+            return a.forward(i["x"])
+    return _S
+
+
+_sa_self_peaked_case("self_attention_d40_self_peaked", 320, 320, 8, 3.2)
 _sa_case("self_attention_d40", 256, 320, 8, False)    # level-0 shape class (S=256 here)
 _sa_case("self_attention_d80", 64, 640, 8, False)
 _sa_case("self_attention_d160", 64, 1280, 8, False)

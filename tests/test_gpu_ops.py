@@ -99,6 +99,34 @@ def test_attention_exact_pass_runs_only_when_a_row_overflows(gpu_ctx, tsd_mod):
         assert_close(y, np.asarray(c.oracle(i), dtype=np.float32), c.tol, c.tol_max, what=name)
 
 
+def test_attention_second_reference_keeps_self_peaked_rows_in_the_optimistic_pass(gpu_ctx, tsd_mod):
+    """Heavy-tailed scores as trained SD self-attention produces them (a token's own key 20+ log2 units above everything in key
+    tile 0): with the tile-0-only reference of round 2 nearly every workgroup repeats exactly (2x on the largest kernel of
+    the step); with the second reference - the row maximum over the query's own 32-key block - none does.  The repeat RATE is
+    asserted, and both paths match the oracle."""
+    from tsd._lib import lib
+    L = lib()
+    c = CASES["self_attention_d40_self_peaked"]
+    i = c.build()
+    ref = np.asarray(c.oracle(i), dtype=np.float32)
+    n_wg = 8 * ((320 + 127) // 128)  # heads x 128-query workgroups (S = 320 runs the 32-queries-per-wave variant)
+    prev = L.tsd_debug_set_attn_diag(0)
+    try:
+        L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+        y0 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+        n0 = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+        L.tsd_debug_set_attn_diag(1)
+        y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+        n1 = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+    finally:
+        L.tsd_debug_set_attn_diag(prev)
+    print(f"[parity] self-peaked scores: exact repeats {n0}/{n_wg} workgroups with the tile-0 reference, {n1}/{n_wg} with the own-block reference")
+    assert n0 >= n_wg // 2, n0          # the round-2 reference repeats (at least the workgroups beyond key tile 0)
+    assert n1 == 0, n1                  # the second reference keeps every row inside fp16
+    assert_close(y0, ref, c.tol, c.tol_max, what="self-peaked scores, tile-0 reference (exact repeat)")
+    assert_close(y1, ref, c.tol, c.tol_max, what="self-peaked scores, own-block reference (optimistic pass)")
+
+
 def test_mfma_sustained_probe_reports_a_plausible_ceiling(gpu_ctx):
     """tsd_debug_mfma_sustained: register-resident fp16 MFMA loop; the figure bench.py prints next to the nominal 2.5 PF."""
     import ctypes as C
