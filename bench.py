@@ -84,13 +84,50 @@ def broadcast_weights(models, rank, world, device, backend="nccl"):
     return time.time() - t0, nbytes
 
 
+def exchange_unique_id(rank, make_id):
+    """Rank 0's 128-byte RCCL unique id to every rank through the existing torch.distributed control plane (whatever its
+    backend: the id is a host byte string).  `make_id()` is called on rank 0 only."""
+    import torch.distributed as dist
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    uid = bytes(box[0])
+    assert len(uid) == 128, len(uid)
+    return uid
+
+
+def broadcast_weights_native(models, ctx, rank, world):
+    """TSD_BENCH_NATIVE_DIST=1: the library's OWN RCCL path (`tsd_dist_init` / `tsd_dist_broadcast_weights`, include/tsd.h) -
+    what a Mojo host without torch would call; torch.distributed only carries the 128-byte unique id.  Failures raise."""
+    from tsd._lib import check, lib
+    t0 = time.time()
+    uid = exchange_unique_id(rank, lambda: _native_unique_id())
+    buf = ctypes.create_string_buffer(uid, 128)
+    check(lib().tsd_dist_init(ctx.h, rank, world, buf))
+    nbytes = 0
+    for m in models:
+        check(lib().tsd_dist_broadcast_weights(m.h, 0))
+        if rank != 0:
+            m.mark_loaded()
+        nbytes += m.packed_blob()[1]
+    ctx.synchronize()
+    check(lib().tsd_dist_finalize(ctx.h))
+    return time.time() - t0, nbytes
+
+
+def _native_unique_id():
+    from tsd._lib import check, lib
+    uid = ctypes.create_string_buffer(128)
+    check(lib().tsd_dist_unique_id(uid))
+    return uid.raw
+
+
 def pmc_traffic_per_gemm_launch():
     """(HBM bytes per gemm_kernel launch, source file) from the newest committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes over this same command, scripts/gpu_pmc_bench.sh -> profiles/rNN_pmc_hbm_traffic.txt),
     with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads -> x2).
     (None, None) when no profile is committed: bench.py itself never runs a profiler, so the figure is NOT measured by
     this run - `traffic_source` in the JSON line says which file it came from."""
-    for name in ("r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
+    for name in ("r03_pmc_hbm_traffic.txt", "r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             fetch = write = launches = 0.0
@@ -188,9 +225,13 @@ def main():
         models = [unet.model] + ([dec.model] if dec is not None else [])
         # a failed broadcast is FATAL: a multi-GPU run that silently re-initialised every rank from the seed would hide
         # exactly the failure the run exists to detect
-        bcast_s, bcast_bytes = broadcast_weights(models, rank, world, f"cuda:{dev_index}", backend)
-        bcast_how = ("rccl broadcast of the packed blobs from rank 0 (in place, zero-copy view of the blob)" if backend == "nccl"
-                     else f"{backend} broadcast of the packed blobs from rank 0 through host memory")
+        if os.environ.get("TSD_BENCH_NATIVE_DIST") == "1":
+            bcast_s, bcast_bytes = broadcast_weights_native(models, ctx, rank, world)
+            bcast_how = "rccl broadcast of the packed blobs from rank 0 by libtsd itself (tsd_dist_*; unique id over torch.distributed)"
+        else:
+            bcast_s, bcast_bytes = broadcast_weights(models, rank, world, f"cuda:{dev_index}", backend)
+            bcast_how = ("rccl broadcast of the packed blobs from rank 0 (in place, zero-copy view of the blob)" if backend == "nccl"
+                         else f"{backend} broadcast of the packed blobs from rank 0 through host memory")
 
     # synthetic inputs: global batch of world*B independent prompts, this rank's contiguous shard
     lo, hi = shard_range(world * B, rank, world)
@@ -227,11 +268,17 @@ def main():
     dt = time.perf_counter() - t0
     # flash-attention workgroups that had to repeat their softmax exactly inside the timed region (kernels_attn.hip)
     attn_exact_wg = _tsd_lib().tsd_debug_attn_exact_passes(ctx.h, 1)
+    rank_rate = (K / (ev_ms * 1e-3), K / (ev_ms * 1e-3))  # (min, max) over ranks of this rank's own steps/s (device events)
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
+        dd = f"cuda:{dev_index}" if backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=dd)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # stragglers: every rank's own rate from its device events, min and max over ranks (a real 8-GPU run shows them here)
+        rr = torch.tensor([K / (ev_ms * 1e-3), -K / (ev_ms * 1e-3)], dtype=torch.float64, device=dd)
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        rank_rate = (-float(rr[1].item()), float(rr[0].item()))
     out_lat = sess.latents()
     finite = bool(np.isfinite(out_lat).all())
 
@@ -413,8 +460,10 @@ def main():
             "img2img_config4": None if enc_ms is None else {
                 "workload": f"VAE encoder on {B} x (3,{8 * L},{8 * L}) + {int(n_sched * 0.6)} UNet steps + VAE decoder (BASELINE configs[3])",
                 "encode_ms_host_boundary": round(enc_ms, 3), "encode_ms_device": round(enc_dev_ms, 3), "steps": int(n_sched * 0.6),
-                "images_per_s": round(world * B / ((enc_dev_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4),
-                "images_per_s_host_boundary_encode": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
+                # images_per_s keeps its round-1 definition (encoder timed through the host boundary: upload + kernels + gaps);
+                # the device-only figure has its own key
+                "images_per_s": round(world * B / ((enc_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4),
+                "images_per_s_device_encode": round(world * B / ((enc_dev_ms + int(n_sched * 0.6) * ms_per_step + dec_ms) / 1e3), 4)},
             # the VAE halves of the hot path against the fp16 MFMA peak (algorithmic GFLOP per image: SURVEY.md Appendix B)
             "vae_roofline": {
                 "decoder": None if dec_ms is None else {
@@ -428,6 +477,7 @@ def main():
             "sd15_config5": sd15,
             "event_ms_per_step": round(ev_ms / K, 4), "output_finite": finite,
             "frac_of_fp16_mfma_peak_whole_step": round(whole_frac, 4),
+            "per_rank_steps_per_s": {"min": round(rank_rate[0], 3), "max": round(rank_rate[1], 3)},
             "weight_broadcast_s": round(bcast_s, 4), "weight_broadcast_bytes": bcast_bytes, "weight_broadcast": bcast_how,
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -620,6 +620,22 @@ def test_splitk_handoff(gpu_ctx, tsd_mod, diffusion):
     assert lib().tsd_debug_xcd_round_robin() in (0, 1)   # informational: same-XCD pairing is a speed choice only
 
 
+def test_bench_native_rccl_broadcast_single_rank(gpu_ctx):
+    """bench.py with TSD_BENCH_NATIVE_DIST=1: the weight blobs go through the library's own tsd_dist_init /
+    tsd_dist_broadcast_weights (unique id exchanged over torch.distributed) - one rank on this box; the JSON line names the
+    path and carries the per-rank rate spread."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSD_BENCH_FORCE_DIST="1", TSD_BENCH_NATIVE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["output_finite"] and d["value"] > 10 and "libtsd itself" in d["weight_broadcast"] and d["weight_broadcast_bytes"] > 5e8
+    assert d["per_rank_steps_per_s"]["min"] == d["per_rank_steps_per_s"]["max"] > 10
+
+
 def test_native_rccl_path_single_rank(gpu_ctx, tsd_mod):
     """The library's own RCCL weight broadcast (`tsd_dist_*`, librccl resolved with dlopen) on a one-rank communicator:
     init -> ncclBroadcast of the packed blob -> finalize must succeed and leave the weights untouched."""

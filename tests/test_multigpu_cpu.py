@@ -55,6 +55,11 @@ def _worker(rank, world, port, out):
     except RuntimeError:
         pass
     del os.environ["TSD_BENCH_FAIL_BCAST"]
+    # the native-RCCL path's control step: rank 0's 128-byte unique id reaches every rank (bench.exchange_unique_id);
+    # make_id must run on rank 0 only
+    calls = []
+    uid = bench.exchange_unique_id(rank, lambda: (calls.append(1), bytes(range(128)))[1])
+    ok_blob = ok_blob and uid == bytes(range(128)) and len(calls) == (1 if rank == 0 else 0)
     # batch shards of a global batch of world*8 prompts
     lo, hi = bench.shard_range(world * 8, rank, world)
     ids = torch.zeros(world * 8, dtype=torch.int64)
