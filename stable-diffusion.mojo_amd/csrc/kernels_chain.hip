@@ -31,6 +31,10 @@
 #include "common.h"
 #include "lds_dma.h"
 
+#ifndef TSD_CHAIN_PIPE
+#define TSD_CHAIN_PIPE 1  // 0 = the round-2 per-chunk GEGLU loop (A/B builds)
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -173,20 +177,40 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     if (seg == 0) { live = gi < SEG0_TILES; return gi * TILE_FULL; }
     if (gi < 10) return SEG0_BYTES + gi * TILE_FULL;
     if (gi < 150) {
+#if TSD_CHAIN_PIPE
+      // visiting order W1(0) | W1(1) W2(0) | W1(2) W2(1) | ... | W1(9) W2(8) | W2(9): chunk j's activation is computed under the
+      // MFMAs of chunk j-1's second GEMM (the packed image keeps its [W1(j), W2(j)] layout - only the walk changes)
+      const int q = gi - 10;
+      int jc, r; bool second;
+      if (q < 10) { jc = 0; r = q; second = false; }
+      else if (q < 136) { const int pq = (q - 10) / 14, pr = (q - 10) - 14 * pq; second = pr >= 10; jc = second ? pq : pq + 1; r = second ? pr - 10 : pr; }
+      else { jc = 9; r = q - 136; second = true; }
+      const int base = SEG0_BYTES + 10 * TILE_FULL + jc * FFN_CHUNK_BYTES;
+      if (!second) { g1 = true; return base + r * TILE_G1; }
+      return base + 10 * TILE_G1 + r * TILE_FULL;
+#else
       const int q = gi - 10, jc = q / 14, r = q - 14 * jc;
       const int base = SEG0_BYTES + 10 * TILE_FULL + jc * FFN_CHUNK_BYTES;
       if (r < 10) { g1 = true; return base + r * TILE_G1; }
       return base + 10 * TILE_G1 + (r - 10) * TILE_FULL;
+#endif
     }
     live = gi < SEG1_TILES;
     return SEG0_BYTES + 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES + (gi - 150) * TILE_FULL;
   };
+#ifdef TSD_CHAIN_NODMA  // ablation build: zero-size descriptor = no weight traffic (results are wrong, the timing is the point)
+  const rsrc_t rw = make_rsrc(p.wstream, 0), rdead = make_rsrc(p.wstream, 0);
+#else
   const rsrc_t rw = make_rsrc(p.wstream, KIND == KIND_HEAD ? HEAD_STREAM_BYTES : STREAM_BYTES), rdead = make_rsrc(p.wstream, 0);
+#endif
   const unsigned lane16 = lane * 16;
   // piece i (of 5 per wave) of tile gi -> ring slot: 1-KiB wave-instruction number wave + 4*i of the tile image
   auto piece = [&](int off, bool g1, bool live, int slot, int i) {
     const int j = wave + 4 * i;
     const bool on = live && !(g1 && j >= 16);
+#ifdef TSD_CHAIN_NOPIECE  // ablation build: no DMA instructions at all after the first tiles of segment 1 (timing only)
+    if (off >= SEG0_BYTES + 12 * TILE_FULL) return;
+#endif
     blds16(on ? rw : rdead, lane16, (unsigned)(off + j * 1024), smem + RING_OFF + slot * SLOT + j * 1024);
   };
   int gt = 0, sl = 0;  // tile counter within the segment ; ring slot of tile gt
@@ -664,6 +688,169 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 10; b++) acc2[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+#if TSD_CHAIN_PIPE
+  {
+    // ONE software pipeline over the 140 GEGLU tiles (round 3).  Round 2 ran per chunk GEMM-1 (10 tiles) -> a * gelu(g) ->
+    // GEMM-2 (4 tiles) as three serial phases: every GEMM call opened with a read-only step and closed with an MFMA-only step,
+    // and the 32 activations per lane ran with the matrix pipe idle - 9.8 K ticks per chunk for 3.8 K of MFMA.
+    // Here a step = barrier of tile gt, the MFMAs of tile gt-1 (whatever GEMM it belongs to) from one fragment register set,
+    // the fragment reads of tile gt into the other, the DMA of tile gt+4 - straight through the walk
+    //   G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(9) G2(8) | G2(9)
+    // and chunk j's activation is computed 8 values per step under the 20 MFMAs of G2(j-1)'s tiles (the accumulator of G1(j)
+    // is complete by then and G1(j+1) has not started), kept in 16 registers, and written to the activation tile at the second
+    // step of G1(j+1) - two barriers after G2(j-1)'s last read of that tile, nine steps before G2(j)'s first.  Same products
+    // in the same order as round 2: bit-identical results.
+    f4 b1v[8];
+    h8 oreg[2][2];
+    h8 afS[2][2], wfS[2][10];
+    auto load_b1 = [&](int jc) {
+      const float* bp = p.b1 + jc * 256 + wn * 128 + g * 32;
+#pragma unroll
+      for (int b = 0; b < 8; b++) b1v[b] = *(const f4*)(bp + b * 4);
+    };
+    auto act_unit = [&](int u, int j0, int j1) {  // elements j0..j1-1 of unit u = (a, q): 8 activations = one 16-B chunk
+      const int a = u >> 1, q = u & 1;
+#pragma unroll
+      for (int j = j0; j < j1; j++) {
+        const int b = q * 4 + (j >> 1), r = (j & 1) * 2;
+        oreg[a][q][j] = (half_t)((acc[a][b][r] + b1v[b][r]) * gelu_tanh_c(acc[a][b][r + 1] + b1v[b][r + 1]));
+      }
+    };
+    auto write_act = [&]() {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          *(h8*)(smem + ACT_OFF + wn * A_KT + (wm * 32 + a * 16 + rsel) * 128 + (((g * 2 + q) ^ key) << 4)) = oreg[a][q];
+    };
+    constexpr int F_ZERO = 1, F_EXTRA = 2, F_WRITE = 4, F_PLAIN = 8;
+    // PK / CK: kind of the previous / current tile (0 none, 1 = GEMM-1 tile: 256 rows, FN 8, A from the LN tile ; 2 = GEMM-2
+    // tile: 320 rows, FN 10, A from the activation tile) ; KC: index of the current tile in its GEMM ; SET: fragment register
+    // set the current tile's fragments go to ; FILL: activation unit computed under this step's MFMAs (-1 none)
+    auto gstep = [&](auto pk_c, auto ck_c, auto kc_c, auto set_c, auto fill_c, auto flags_c) {
+      constexpr int PK = decltype(pk_c)::value, CK = decltype(ck_c)::value, KC = decltype(kc_c)::value, SET = decltype(set_c)::value;
+      constexpr int FILL = decltype(fill_c)::value, FLAGS = decltype(flags_c)::value;
+      constexpr int FNp = PK == 1 ? 8 : 10, FNc = CK == 1 ? 8 : 10;
+      bool g1n = false, liven = false;
+      int off = 0, s4 = 0;
+      const char *sA = smem, *sW = smem;
+      if constexpr (CK != 0) {
+        int younger = 0;
+#pragma unroll
+        for (int d = 1; d <= 3; d++) { bool yg1, ylive; tile_off(1, gt + d, yg1, ylive); younger += yg1 ? 4 : 5; }
+        constexpr int EX = (FLAGS & F_EXTRA) ? 8 : 0;
+        switch (younger) {
+          case 12: wait_vm<12 + EX>(); break;
+          case 13: wait_vm<13 + EX>(); break;
+          case 14: wait_vm<14 + EX>(); break;
+          default: wait_vm<15 + EX>(); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile gt-1 (and any activation-tile writes) are complete
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        sA = smem + (CK == 1 ? A_OFF : ACT_OFF) + (KC >> 1) * A_KT + a_rd + ((((KC & 1) * 4 + g) ^ key) << 4);
+        sW = smem + RING_OFF + sl * SLOT + wn * (FNc == 10 ? 10240 : 8192) + w_rd;
+        off = tile_off(1, gt + 4, g1n, liven);
+        s4 = sl == 0 ? 4 : sl - 1;
+      }
+      if constexpr ((FLAGS & F_WRITE) != 0) write_act();
+      h8 (&af)[2] = afS[SET];
+      h8 (&wf)[10] = wfS[SET];
+      const h8 (&paf)[2] = afS[SET ^ 1];
+      const h8 (&pwf)[10] = wfS[SET ^ 1];
+      if constexpr (PK == 0) {
+        if constexpr (CK != 0) {
+#pragma unroll
+          for (int a = 0; a < 2; a++) af[a] = *(const h8*)(sA + a * 2048);
+#pragma unroll
+          for (int b = 0; b < FNc; b++) wf[b] = *(const h8*)(sW + b * 1024);
+#pragma unroll
+          for (int i = 0; i < 5; i++) if (!(g1n && i == 4)) piece(off, g1n, liven, s4, i);
+        }
+      } else {
+        constexpr int NM = 2 * FNp, NR = CK != 0 ? 2 + FNc : 0;
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+          const int b = q >> 1, a = q & 1;
+          const f4 c0 = (FLAGS & F_ZERO) ? f4{0.f, 0.f, 0.f, 0.f} : (PK == 1 ? acc[a][b] : acc2[a][b]);
+          const f4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], c0, 0, 0, 0);
+          if (PK == 1) acc[a][b] = d; else acc2[a][b] = d;
+          __builtin_amdgcn_sched_barrier(0);
+          if (q < NR) {
+            if (q < 2) af[q] = *(const h8*)(sA + q * 2048);
+            else wf[q - 2] = *(const h8*)(sW + (q - 2) * 1024);
+          }
+          if (CK != 0 && (q + 1) % (NM / 5) == 0 && (q + 1) / (NM / 5) - 1 < 5) {
+            const int i = (q + 1) / (NM / 5) - 1;
+            if (!(g1n && i == 4)) piece(off, g1n, liven, s4, i);
+          }
+          // one activation after every second MFMA (8 per step)
+          if (FILL >= 0 && (q & 1) && (q >> 1) < 8) act_unit(FILL, q >> 1, (q >> 1) + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr ((FLAGS & F_PLAIN) != 0) {  // chunk 0: nothing to hide its activation under
+#pragma unroll
+        for (int u = 0; u < 4; u++) act_unit(u, 0, 8);
+        write_act();
+      }
+      if constexpr (CK != 0) {
+        gt++;
+        sl = sl == 4 ? 0 : sl + 1;
+      }
+    };
+    using IM1 = std::integral_constant<int, -1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    using I7 = std::integral_constant<int, 7>;
+    using I9 = std::integral_constant<int, 9>;
+    // ---- G1(0): tiles 0..9 (bias of chunk 0 in flight under its first four steps) ----
+    load_b1(0);
+    gstep(I0{}, I1{}, I0{}, I0{}, IM1{}, I2{});                 // flags: EXTRA
+    gstep(I1{}, I1{}, I1{}, I1{}, IM1{}, I3{});                 // ZERO (first product of the chunk) + EXTRA
+    gstep(I1{}, I1{}, I2{}, I0{}, IM1{}, I2{});
+    gstep(I1{}, I1{}, I3{}, I1{}, IM1{}, I2{});
+    gstep(I1{}, I1{}, I4{}, I0{}, IM1{}, I0{});
+    gstep(I1{}, I1{}, I5{}, I1{}, IM1{}, I0{});
+    gstep(I1{}, I1{}, I6{}, I0{}, IM1{}, I0{});
+    gstep(I1{}, I1{}, I7{}, I1{}, IM1{}, I0{});
+    gstep(I1{}, I1{}, I8{}, I0{}, IM1{}, I0{});
+    gstep(I1{}, I1{}, I9{}, I1{}, IM1{}, I0{});
+    for (int j = 1; j < 10; j++) {
+      // ---- G1(j): the first step finishes the previous tile (G1(0)'s last for j = 1: then chunk 0's activation runs in the
+      // open; else G2(j-2)'s last, hiding unit 3 of chunk j-1) ; the second publishes chunk j-1's activations ----
+      if (j == 1) gstep(I1{}, I1{}, I0{}, I0{}, IM1{}, I8{});   // PLAIN: all of chunk 0's activation + write
+      else gstep(I2{}, I1{}, I0{}, I0{}, I3{}, I0{});
+      if (j == 1) gstep(I1{}, I1{}, I1{}, I1{}, IM1{}, I1{});   // ZERO
+      else gstep(I1{}, I1{}, I1{}, I1{}, IM1{}, I5{});          // ZERO + WRITE
+      gstep(I1{}, I1{}, I2{}, I0{}, IM1{}, I0{});
+      gstep(I1{}, I1{}, I3{}, I1{}, IM1{}, I0{});
+      gstep(I1{}, I1{}, I4{}, I0{}, IM1{}, I0{});
+      load_b1(j);                                               // used from the second step of G2(j-1) on: six steps from here
+      gstep(I1{}, I1{}, I5{}, I1{}, IM1{}, I2{});               // EXTRA for four steps
+      gstep(I1{}, I1{}, I6{}, I0{}, IM1{}, I2{});
+      gstep(I1{}, I1{}, I7{}, I1{}, IM1{}, I2{});
+      gstep(I1{}, I1{}, I8{}, I0{}, IM1{}, I2{});
+      gstep(I1{}, I1{}, I9{}, I1{}, IM1{}, I0{});
+      // ---- G2(j-1): chunk j's activation units 0..2 under its tiles' MFMAs ----
+      gstep(I1{}, I2{}, I0{}, I0{}, IM1{}, I0{});
+      gstep(I2{}, I2{}, I1{}, I1{}, I0{}, I0{});
+      gstep(I2{}, I2{}, I2{}, I0{}, I1{}, I0{});
+      gstep(I2{}, I2{}, I3{}, I1{}, I2{}, I0{});
+    }
+    // ---- G2(8)'s last tile with unit 3 of chunk 9, publish, then G2(9) ----
+    gstep(I2{}, I0{}, I0{}, I0{}, I3{}, I0{});
+    write_act();
+    gstep(I0{}, I2{}, I0{}, I0{}, IM1{}, I0{});
+    gstep(I2{}, I2{}, I1{}, I1{}, IM1{}, I0{});
+    gstep(I2{}, I2{}, I2{}, I0{}, IM1{}, I0{});
+    gstep(I2{}, I2{}, I3{}, I1{}, IM1{}, I0{});
+    gstep(I2{}, I0{}, I0{}, I0{}, IM1{}, I0{});
+  }
+#else
   for (int jc = 0; jc < 10; jc++) {
     if (jc == 5) CTS(10);
     f4 b1v[8];  // this chunk's (a, g) bias pairs: in flight under the chunk's first GEMM
@@ -694,6 +881,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     gemm(I10{}, I1{}, No{}, I0{}, acc2, ACT_OFF, 4, No{});
     if (jc == 5) CTS(13);
   }
+#endif
   CTS(7);
   load_cols(p.b2, bv);
 #pragma unroll
