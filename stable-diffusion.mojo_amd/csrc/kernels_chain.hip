@@ -982,6 +982,8 @@ int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   if (a.ld_ao % 8 || a.ld_tok % 8 || a.ld_x % 8 || a.ld_out % 8 || a.ldk % 8 || a.ldvt % 8 || a.ld_ao < 320 || a.ld_tok < 320 ||
       a.ld_x < 320 || a.ld_out < 320 || a.ldk < 320 || a.ldvt < ((a.T + 7) & ~7))
     TSD_FAIL(TSD_E_SHAPE, "attention tail: misaligned or too narrow pitches");
+  // the ao tile is DMA'd through ONE descriptor based at a.ao with 32-bit byte offsets (m0 + row) * ld_ao * 2
+  if ((long long)a.M * a.ld_ao * 2 >= 0x7ffffff0LL) TSD_FAIL(TSD_E_SHAPE, "attention tail: ao operand exceeds the 2 GiB addressing window");
   if (!a.ao || !a.tok || !a.x || !a.out || !a.Kc || !a.Vt || !a.bso || !a.bco || !a.b1 || !a.b2 || !a.bout)
     TSD_FAIL(TSD_E_ARG, "attention tail: NULL operand");
   if (!ctx->launch()) return TSD_OK;
