@@ -323,8 +323,8 @@ def main():
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<...> (dense + conv3x3 implicit GEMM)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else f"{traffic_src} (separate rocprofv3 --pmc passes of an earlier "
-                                      "build; NOT measured by this run)",
+                    "traffic_source": None if traffic is None else f"{traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes over this same command, scripts/gpu_pmc_bench.sh; committed file, NOT measured by this run)",
                     "launches_per_step": gemm_launches, "avg_launch_us": round(1e3 * gemm_ms / max(1, gemm_launches), 2),
                     "algorithmic_gflop_per_step": round(gemm_gf_step, 1),
                     "event_overhead_us_per_launch_removed": round(1e3 * ev_overhead_ms, 3),
