@@ -35,7 +35,8 @@
 #include "lds_dma.h"
 
 // Ablation builds of the attention core (timing only, results wrong): bit 0 no exponentials, bit 1 no P.V MFMAs, bit 2 no
-// QK^T MFMAs, bit 3 s_setprio(1) around the QK^T MFMAs, bit 4 s_setprio(1) around the P.V / exponential region
+// QK^T MFMAs, bit 3 s_setprio(1) around the QK^T MFMAs, bit 4 s_setprio(1) around the P.V / exponential region, bit 5 no per-tile
+// barrier, bit 6 no per-tile DMA wait and no barrier, bit 7 no tile DMA at all
 #ifndef TSD_ATTN_ABL
 #define TSD_ATTN_ABL 0
 #endif
@@ -196,6 +197,9 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
   }
 
   auto stage = [&](int t, int buf) {
+#if TSD_ATTN_ABL & 128
+    if (t > 0) return;
+#endif
     char* sK = smem + buf * BUF_BYTES;
     char* sV = sK + K_BYTES;
     const int k0 = t * 64;
@@ -401,8 +405,13 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
 #pragma unroll
       for (int qb = 0; qb < QB; qb++) l_run[qb] += psum2[qb][0] + psum2[qb][1];
     }
+#if TSD_ATTN_ABL & 32   // ablation: no per-tile barrier (each wave only waits for its own DMA pieces)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif TSD_ATTN_ABL & 64 // ablation: neither the DMA wait nor the barrier
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
   }
   };
   // row sum l: row D of O^T when V^T carries the ones row (it sits in the hi=0 lane of each query's lane pair)
