@@ -751,6 +751,17 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       // (clamped addresses) so exactly RES_LOADS VMEM instructions are younger than the last DMA.
       constexpr int RES_LOADS = (FM / 2) * ITEMS;
       h8 resv[FM / 2][ITEMS];
+      // the lane's column biases are fetched here too (older than the residual loads, so the counted wait below covers them): loaded
+      // inside the pass loop their L2 / HBM round trip sat in front of the first transpose of every block
+      // (not in the 12-wave staggered tiles: 168 registers per wave, the 20 extra ones spill)
+      constexpr bool PREBIAS = !(LW > 0 && NW == 8);
+      f4 bvn[FN];
+#pragma unroll
+      for (int b = 0; b < FN; b++) bvn[b] = f4{0.f, 0.f, 0.f, 0.f};
+      if (PREBIAS && (epi & EPI_BIAS_N)) {
+#pragma unroll
+        for (int b = 0; b < FN; b++) bvn[b] = *(const f4*)(p.bias + min(nb + b * 4, p.N - 4));
+      }
       if (epi & EPI_RESIDUAL) {
         const half_t* rbase = p.R + (long long)bz * p.sR;
 #pragma unroll
@@ -784,9 +795,6 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       for (int pass = 0; pass < FM / 2; pass++) {
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-          // one 16-row fragment block at a time: left to itself the scheduler hoists the bias / row-vector loads of every
-          // unrolled (pass, hf) iteration to the top of the epilogue and spills (3848 scratch accesses in the 128x160 conv kernel)
-          __builtin_amdgcn_sched_barrier(0);
           const int a = pass * 2 + hf;
           const int m = m0 + wm * BMw + a * 16 + rsel;
           float v[4 * FN];
@@ -804,7 +812,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
           if (epi & EPI_BIAS_N) {
 #pragma unroll
             for (int b = 0; b < FN; b++) {
-              const f4 bv = *(const f4*)(p.bias + min(nb + b * 4, p.N - 4));
+              const f4 bv = PREBIAS ? bvn[b] : *(const f4*)(p.bias + min(nb + b * 4, p.N - 4));
 #pragma unroll
               for (int r = 0; r < 4; r++) v[b * 4 + r] += bv[r];
             }
@@ -825,7 +833,6 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         // same-wave LDS operations complete in order: the row-major reads below see the stores above
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-          __builtin_amdgcn_sched_barrier(0);
           const int t = lane + 64 * i;
           const int r = t / CH, c = t - r * CH;
           const int m = m0 + wm * BMw + pass * 32 + r;
