@@ -27,7 +27,9 @@ Act act_alloc_gn(tsd_ctx* ctx, int B, int H, int W, int C, int groups) {
 static void gn_emit(GemmArgs& g, Act* dst, int rows_per_sample) {
   if (!dst || !dst->gn_buf || dst->gn_groups <= 0 || g.N != dst->C || (g.epi & (EPI_OUT_F32 | EPI_GEGLU))) return;
   const int ns = gemm_gnstats_slabs(g.M, g.N, g.K, g.batch, g.conv, rows_per_sample, dst->gn_groups);
-  if (ns <= 0 || ns > ceil_div(rows_per_sample, 32) || ns > 128) return;  // every apply block re-reduces the slabs: keep them few
+  // up to 128 slabs the apply blocks (or k_gn_finalize) reduce them directly; beyond 256 (the VAE's 128^2 ... 512^2 images)
+  // launch_groupnorm pre-reduces them to 64 chunks per sample (k_gn_prereduce) - either way no statistics pass over the tensor
+  if (ns <= 0 || ns > ceil_div(rows_per_sample, 32) || (ns > 128 && ns <= 256) || dst->gn_groups > 256) return;
   g.epi |= EPI_GNSTATS;
   g.gn_part = dst->gn_buf; g.gn_groups = dst->gn_groups; g.gn_rows_per_sample = rows_per_sample; g.gn_nslab = ns;
   dst->gn_part = dst->gn_buf; dst->gn_nslab = ns;

@@ -144,6 +144,35 @@ __device__ __forceinline__ void gn_finish_groups(const GnK& p, int b, int g0, in
   }
 }
 
+// Producer-emitted partials of a LARGE image (VAE: 512 ... 8192 slabs of 32 rows per sample): 64 blocks per sample each add
+// nslab/64 consecutive slabs per group - fixed order, double accumulation - into a 64-"slab" table the apply blocks re-reduce
+// themselves.  Replaces the statistics pass over the tensor (k_gn_partial: one more read of up to 537 MB) by a read of a few MB.
+__global__ __launch_bounds__(256) void k_gn_prereduce(const float* __restrict__ part, int nslab, int G, float* __restrict__ out) {
+  const int b = blockIdx.y, c = blockIdx.x, nchunk = gridDim.x;
+  const int s0 = (int)(((int64_t)c * nslab) / nchunk), s1 = (int)(((int64_t)(c + 1) * nslab) / nchunk);
+  // thread -> (group g, lane l of LN lanes striding the chunk's slabs); 2 floats per (slab, group)
+  const int LN = 256 / G > 0 ? 256 / G : 1;
+  __shared__ double red[256][2];
+  for (int g0 = 0; g0 < G; g0 += 256) {
+    const int g = g0 + (int)threadIdx.x % (G < 256 ? G : 256), l = (int)threadIdx.x / (G < 256 ? G : 256);
+    double t1 = 0.0, t2 = 0.0;
+    if (g < G && l < LN)
+      for (int sidx = s0 + l; sidx < s1; sidx += LN) {
+        const float* o = part + (((int64_t)b * nslab + sidx) * G + g) * 2;
+        t1 += (double)o[0];
+        t2 += (double)o[1];
+      }
+    red[threadIdx.x][0] = t1; red[threadIdx.x][1] = t2;
+    __syncthreads();
+    if (l == 0 && g < G) {
+      for (int k = 1; k < LN; k++) { t1 += red[threadIdx.x + k * G][0]; t2 += red[threadIdx.x + k * G][1]; }  // fixed order
+      float* o = out + (((int64_t)b * nchunk + c) * G + g) * 2;
+      o[0] = (float)t1; o[1] = (float)t2;
+    }
+    __syncthreads();
+  }
+}
+
 // Separate finalize launch, used when (slabs x groups) is large: then every apply block re-reducing the partials would
 // read as much as its payload (128 slabs x 32 groups = 32 KB per 30 KB of pixels at 320x64^2; 10x that for the output
 // layer's 320 groups).  One block per (32 groups, sample).
@@ -243,7 +272,9 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   k.apply_pixels = apply_mult * GN_UNROLL * PL;
   // statistics already emitted by the producer's epilogue (EPI_GNSTATS, same [B][nslab][G][2] layout): no partial pass
   const bool have_stats = pre_part != nullptr && pre_nslab > 0;
-  if (have_stats) { k.partial = const_cast<float*>(pre_part); k.nslab = pre_nslab; }
+  const bool prereduce = have_stats && pre_nslab > 256 && groups <= 256;  // large images (VAE): 64 chunks per sample first
+  if (have_stats && !prereduce) { k.partial = const_cast<float*>(pre_part); k.nslab = pre_nslab; }
+  else if (prereduce) { k.partial = arena_alloc<float>(ctx, (int64_t)B * 64 * groups * 2); k.nslab = 64; }
   else k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
   k.stats = arena_alloc<float>(ctx, (int64_t)B * groups * 2);
   if (!k.partial || !k.stats) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
@@ -253,6 +284,9 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
   if (!have_stats) {
     hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
+    HIP_TRY(hipGetLastError());
+  } else if (prereduce) {
+    hipLaunchKernelGGL(k_gn_prereduce, dim3(64, B), dim3(256), 0, ctx->stream, pre_part, pre_nslab, groups, k.partial);
     HIP_TRY(hipGetLastError());
   }
   k.stats_ready = (int64_t)k.nslab * groups >= 2048 ? 1 : 0;
