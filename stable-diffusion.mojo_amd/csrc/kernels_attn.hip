@@ -24,8 +24,9 @@
 //   * head dims that are not a multiple of 16 (d=40) are zero-padded per 16-B chunk by the DMA's range check /
 //     a padded offset; LDS row pitches are odd multiples of 16 B (K) / XOR-swizzled (V^T)
 //     so all ds_read_b128 are bank-conflict-free.
-//   * the 4096 x 4096 d = 40 call is power-bound (shader clock 1.2-1.5 GHz under it, profiles/r02_flash_clock.txt):
-//     what pays is fewer LDS reads and fewer VALU ops, not issue slots.
+//   * the 4096 x 4096 d = 40 call: matrix pipe 55 % busy at 1.97-2.0 GHz (GRBM_GUI_ACTIVE / SQ_BUSY_CYCLES, profiles/r03_pmc_clock.txt -
+//     the round-2 "power-bound at 1.2-1.5 GHz" reading is withdrawn); the ablation builds below (TSD_ATTN_ABL) show MFMA time, fragment
+//     reads, DMA issue and plain VALU work of a SIMD's waves adding up, with the exponentials and the per-tile barrier free.
 #include <stdlib.h>
 
 #include <vector>
@@ -525,9 +526,8 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   k.diag = (g_attn_diag && a.Sq == a.Sk) ? 1 : 0;
   switch (a.d) {
     case 40:
-      // 64 queries per wave when that still fills the chip (2 workgroups per CU resident) and the key loop is long enough
-      // to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (shader clock 1.21 -> 1.46 GHz: the call is power-bound and
-      // half the LDS reads is what buys the clock); 77-key cross attention is better off with the 128-query workgroup
+      // 64 queries per wave when the key loop is long enough to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (half the
+      // K / V^T fragment reads per MFMA); 77-key cross attention is better off with the 128-query workgroup
       // The choice keys on the layer (Sq, Sk, H), never on the batch: the two variants are bitwise equal only while no
       // workgroup repeats exactly (the repeat is decided per 128- / 256-query workgroup and moves the reference per 32 / 64
       // rows), so a sample computed alone must run the same variant as its row of a batch (bitwise batch invariance).

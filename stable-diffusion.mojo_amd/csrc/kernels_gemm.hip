@@ -23,6 +23,8 @@
 //     transpose to row-major so loads/stores are 16 B per lane over whole row segments; optional GroupNorm
 //     statistics (EPI_GNSTATS) for the consumer norm; split-K hand-off through the XCD-local L2 for the 16x16 level.
 //   * XCD-aware block -> tile map: the 8 XCDs own an (8/xn) x xn grid of the tile space chosen by operand footprint.
+//   * Round 3: optional loader waves (LW) that issue the block's whole LDS-DMA stream, and with eight compute waves the staggered
+//     two-group schedule (tile configurations 51 / 53) - DESIGN.md 4.1 "what a K tile costs".
 #include <math.h>
 #include <stdlib.h>
 
