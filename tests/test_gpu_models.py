@@ -296,6 +296,31 @@ def test_headline_size_matches_oracle(gpu_ctx, tsd_mod, diffusion, unet_params):
         assert_close(out[b], ref, TOL_MODEL, TOL_MODEL_MAX, f"headline size: Diffusion.forward L=64 B=8, sample {b}")
 
 
+def test_cfg_step_at_headline_size_matches_oracle(gpu_ctx, tsd_mod, diffusion, unet_params):
+    """The classifier-free-guidance step at the headline size - a batch-8 session whose UNet call runs 16 samples (other tile
+    configurations than the batch-8 step: twice the rows at every level), CFG combine and DDPM update fused on the device -
+    against the oracle for one sample: eps = s (e_c - e_u) + e_u with both oracle forwards at L = 64 (pipeline.mojo:107-121,
+    sampler.mojo:75-109).  The combine amplifies the fp16 rounding of the two passes by the guidance scale (3 here)."""
+    B, L, scale = 8, 64, 3.0
+    lat, ctx = _inputs(B, L, tag=790)
+    _, uctx = _inputs(B, L, tag=795)
+    noise = rng.normal(SEED, 797, 2 * B * 4 * L * L).reshape(2, B, 4, L, L)
+    s = tsd_mod.Session(diffusion.model, None, B, L, 77, cfg=True)
+    s.set_schedule(1000, 2, 0)
+    s.upload(lat, ctx, uctx, noise, cfg_scale=scale)
+    s.step(0)
+    got = s.latents()
+    s.close()
+    b, t = 5, 500
+    temb = ops.time_embedding(float(t))
+    e_c = models.diffusion(unet_params, lat[b], ctx[b], temb)
+    e_u = models.diffusion(unet_params, lat[b], uctx[b], temb)
+    sm = sampler.DDPMSampler(1000)
+    sm.set_inference_timesteps(2)
+    ref = sm.step(t, lat[b], sampler.cfg_combine(e_c, e_u, scale), noise[0, b])
+    assert_close(got[b], ref, TOL_MODEL, TOL_MODEL_MAX, "headline size: CFG step (UNet batch 16) L=64, sample 5")
+
+
 def test_decoder_512px_matches_oracle(gpu_ctx, tsd_mod, decoder, dec_params):
     """One 512x512 decode (latent 64, vae.mojo:221-250) of a batch of 2 against the oracle at full size."""
     lat = rng.normal(SEED, 720, 2 * 4 * 64 * 64).reshape(2, 4, 64, 64) * 0.18215
