@@ -303,6 +303,10 @@ int tsd_debug_set_attn_qb(int mode);
  * own 32-key block) + headroom; on = 0 restores the tile-0-only reference (to measure what the second reference saves on
  * peaked score distributions).  Returns the previous setting. */
 int tsd_debug_set_attn_diag(int on);
+/* Residual blocks whose skip path is a 1x1 convolution at the block's own resolution (diffusion.mojo:70-72, vae.mojo:65-67) run it
+ * inside the second 3x3 convolution as extra K (on = 1, default); on = 0 runs it as its own GEMM + residual add (the round-2 path,
+ * kept for A/B and for the equivalence test).  Returns the previous setting. */
+int tsd_debug_set_res_fuse_skip(int on);
 /* What this board sustains on the matrix pipe: a register-resident dense fp16 MFMA loop (no LDS, no memory) run for about
  * `ms_target` ms at 4 waves per SIMD; reports the achieved TFLOP/s and the shader clock (GHz) during the run.  The nominal
  * dense peak assumes the boost clock; under matrix-pipe load the board's power limit sets the clock. */

@@ -161,6 +161,10 @@ struct GemmArgs {
   // conv3x3 mode (conv != 0): A0 is NHWC [B][Hs][Ws][lda0]; output pixel m = (b*Ho+oy)*Wo+ox reads
   // tap (kh,kw) at (oy*stride-pad+kh, ox*stride-pad+kw) of the (optionally 2x-upsampled) source.
   int conv = 0, Hs = 0, Ws = 0, Ho = 0, Wo = 0, Cin = 0, stride = 1, pad = 1, ups = 0;
+  // conv3x3 + fused 1x1 convolution of a second tensor at the same resolution (residual block skip path): K = 9*Cin + Cin1 + Cin2,
+  // A1 [.][lda1] gives channels 0..Cin1, A2 [.][lda2] channels Cin1..Cin1+Cin2 (channel concat), weights Wt1[N][ldw1]
+  const half_t* A2 = nullptr; int lda2 = 0; int Cin1 = 0, Cin2 = 0;
+  const half_t* Wt1 = nullptr; int ldw1 = 0;
   const half_t* Wt = nullptr; int ldw = 0;  // "W" operand [N][K]
   int M = 0, N = 0, K = 0;
   int batch = 1; int64_t sA = 0, sW = 0, sC = 0, sR = 0;  // element strides per batch

@@ -36,7 +36,8 @@ static void gn_emit(GemmArgs& g, Act* dst, int rows_per_sample) {
 }
 
 int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, int pad_br, int ups,
-              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy, Act* stat) {
+              const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy, Act* stat,
+              const CatSrc* skip_x, const ConvW* skip_w) {
   if (w.k != 3) TSD_FAIL(TSD_E_SHAPE, "g_conv3x3: kernel size %d", w.k);
   if (x.ld < w.Ipad) TSD_FAIL(TSD_E_SHAPE, "g_conv3x3: input pitch %d < padded Cin %d", x.ld, w.Ipad);
   const int Hin = ups ? 2 * x.H : x.H, Win = ups ? 2 * x.W : x.W;
@@ -53,6 +54,17 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
   if (rowvec) { g.epi |= EPI_ROWVEC; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = Ho * Wo; }
   if (res) { g.epi |= EPI_RESIDUAL | (res_ups ? EPI_RES_UPS : 0); g.R = res->p; g.ldr = res->ld; }
   if (out_f32) g.epi |= EPI_OUT_F32;
+  if (skip_x && skip_w) {
+    // y += conv1x1(skip_x) + skip bias: K runs on past the nine taps over the skip tensor's channels (kernels_gemm.hip "taps" 9 / 10);
+    // the 1x1 bias rides in the per-sample row vector slot with pitch 0
+    if (rowvec || skip_w->k != 1 || skip_w->Opad != w.Opad) TSD_FAIL(TSD_E_ARG, "g_conv3x3: fused skip does not fit");
+    const int ck = skip_w->Ipad;
+    g.A1 = skip_x->p0; g.lda1 = skip_x->ld0; g.Cin1 = (skip_x->p1 && ck > skip_x->C0) ? skip_x->C0 : ck;
+    if (g.Cin1 < ck) { g.A2 = skip_x->p1; g.lda2 = skip_x->ld1; g.Cin2 = ck - g.Cin1; }
+    g.Wt1 = skip_w->w; g.ldw1 = ck;
+    g.K += ck;
+    if (skip_w->b) { g.epi |= EPI_ROWVEC; g.rowvec = skip_w->b; g.rowvec_ld = 0; g.rows_per_batch = Ho * Wo; }
+  }
   g.C = y; g.ldc = ldy;
   g.rows_per_sample_hint = Ho * Wo;
   gn_emit(g, stat, Ho * Wo);
@@ -81,6 +93,13 @@ static NormSrc norm_src(const CatSrc& x, int C) {
   return s;
 }
 
+static int g_res_fuse_skip = -1;  // -1: read TSD_RES_FUSE_SKIP on first use (default on)
+extern "C" int tsd_debug_set_res_fuse_skip(int on) {
+  const int prev = g_res_fuse_skip < 0 ? 1 : g_res_fuse_skip;
+  if (on == 0 || on == 1) g_res_fuse_skip = on;
+  return prev;
+}
+
 // `Unet_Residual_Block.forward` diffusion.mojo:54-72 / VAE `Res_Block.forward` vae.mojo:57-67
 int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
                int tld, Act& out) {
@@ -102,6 +121,16 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(t1), cout), B, H * W, cout, w.groups, w.eps, 1.f, 1, h3.p, h3.ld, t1.gn_part,
                            t1.gn_nslab, w.gn2.w ? &w.gn2 : nullptr));
   Act r;
+  // Skip path `x + ...` / `conv1x1(x) + ...` (diffusion.mojo:70-72, vae.mojo:65-67).  At the block's own resolution the 1x1 convolution
+  // is folded into the second 3x3 convolution as extra K (one launch and one residual read less, and the products run at the
+  // big convolution's rate); behind an upsample it stays a GEMM at the input resolution (a quarter of the rows).
+  if (g_res_fuse_skip < 0) g_res_fuse_skip = getenv("TSD_RES_FUSE_SKIP") ? atoi(getenv("TSD_RES_FUSE_SKIP")) : 1;
+  if (w.has_skip && !ups && g_res_fuse_skip > 0 && w.skip.k == 1 && w.skip.Ipad % 64 == 0 && w.skip.Ipad == cin &&
+      !(x.p1 && cin > x.C0 && (x.C0 % 64))) {
+    TSD_TRY(g_conv3x3(ctx, h3, w.conv2, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, out.p, out.ld, &out, &x, &w.skip));
+    ctx->arena.release(mark);
+    return TSD_OK;
+  }
   if (w.has_skip) {  // 1x1 conv on the raw input, at the INPUT resolution (commutes with nearest upsample)
     r = act_alloc(ctx, B, Hin, Win, cout); CHECK_ALLOC(r.p);
     TSD_TRY(g_linear(ctx, x, (int64_t)B * Hin * Win, w.skip.w, w.skip.Ipad, cout, w.skip.Ipad, w.skip.b, nullptr, 0, 0,

@@ -23,7 +23,8 @@ static inline CatSrc cat2(const Act& a, const Act& b) {
 // y = conv3x3(x) (+bias) (+rowvec per sample) (+residual); `ups`: x is read through a nearest-2x upsample.
 int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, int pad_br, int ups,
               const float* rowvec, int rowvec_ld, const Act* res, int res_ups, bool out_f32, void* y, int ldy,
-              Act* stat = nullptr);  // stat: the output tensor's Act when GroupNorm statistics are wanted
+              Act* stat = nullptr,  // stat: the output tensor's Act when GroupNorm statistics are wanted
+              const CatSrc* skip_x = nullptr, const ConvW* skip_w = nullptr);  // + conv1x1(skip_x) fused as extra K (same resolution)
 // y[M][N] = A[M][K] . W^T (+bias) (+residual) ; A may be a concat view
 int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
              const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat = nullptr, int rows_per_sample = 0);

@@ -63,6 +63,10 @@ struct GemmK {
   int lda0, lda1, K0, ldw, ldr, ldc, rowvec_ld, rows_per_batch;
   int M, N, K;
   int Hs, Ws, Ho, Wo, Cin, stride, pad, ups;
+  // conv3x3 with a fused 1x1 convolution of a second tensor (the residual block's skip path): K continues past the nine taps
+  // with "taps" 9 / 10 = the centre pixel of A1 (Cin1 channels) / A2 (Cin2 channels, the second half of a channel concat),
+  // weights Wt1[n][Cin1 + Cin2]
+  const half_t* A2; const half_t* Wt1; int lda2, Cin1, Cin2, ldw1;
   int epi, tiles_n, xcd_n;
   float out_scale;
   float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
@@ -110,10 +114,13 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // (the one-block-per-CU configurations) the matrix pipe idles for every one of the 4-7 DMA instructions per K tile.  Measured in
 // isolation (scripts/micro/gemm_ws.hip + profiles/r03_micro_gemm_ws.txt): 822 -> 957 TF with loaders, 1137 TF with staggered groups.
 // The loaders run the same ring protocol (counted vmcnt, one barrier per K tile) and end before the epilogue.
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false, bool HX = false, int LW = 0>
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS, bool PP = false, int CV = 0, int LW = 0>
 __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : ((NS <= 2 || WGM * WGN > 4) && FM * FN <= 20 ? 2 : 1)) void gemm_kernel(const GemmK p) {
   constexpr int NW = WGM * WGN;
   constexpr int NI = LW ? LW : NW;  // waves that issue DMA
+  constexpr bool HX = CV == 1;  // conv variant: 1 = halo-x K order, 2 = fused 1x1 skip source (K runs on past the nine taps)
+  constexpr bool SK = CV == 2;
+  static_assert(CV == 0 || CONV, "conv variants");
   static_assert(LW == 0 || (LW == 4 && !PP && !HX), "loader waves: one per SIMD, plain ring schedules only");
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
   constexpr int BMw = FM * 16, BNw = FN * 16;
@@ -169,6 +176,12 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
   const half_t* A0 = p.A0 + (long long)bz * p.sA;
   const half_t* A1 = p.A1 ? p.A1 + (long long)bz * p.sA : nullptr;
   const half_t* Wt = p.Wt + (long long)bz * p.sW;
+  // Fused-skip sources as DIFFERENCES to the main ones, picked by mask arithmetic below.  Written as `c ? A0 : c2 ? A1 : A2`
+  // inside the staging lambdas, hipcc turns the three by-reference captures into one load at a run-time offset into the closure
+  // object; the closure then stays in memory, and with it every variable it refers to - 500-700 B of scratch per lane.
+  const long long dA1 = SK ? (long long)((uintptr_t)p.A1 - (uintptr_t)p.A0) : 0, dA2 = SK ? (long long)((uintptr_t)p.A2 - (uintptr_t)p.A0) : 0;
+  const long long dW1 = SK ? (long long)((uintptr_t)p.Wt1 - (uintptr_t)p.Wt) : 0;
+  const unsigned k_lda1 = (unsigned)p.lda1, k_dlda2 = (unsigned)(p.lda2 - p.lda1), k_ldw1 = (unsigned)p.ldw1, k_cin1 = (unsigned)p.Cin1;
 
   const int lrow = lane >> 3;
   const int cch = (lane & 7) ^ lrow;  // logical 16-B chunk this lane fetches (source-side swizzle)
@@ -225,7 +238,13 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
 
   // conv: running (tap, channel-chunk) of the NEXT tile to stage
   const int cpt = CONV ? (p.Cin >> 6) : 1;
+  const int cpt1 = SK ? (p.Cin1 >> 6) : 0, cpt2 = SK ? (p.Cin2 >> 6) : 0;  // fused 1x1 skip sources
+  const int ntaps = SK ? 9 + (cpt1 > 0) + (cpt2 > 0) : 9;
   int st_tap = kt0 / cpt, st_cc = kt0 - (kt0 / cpt) * cpt;
+  if (SK && kt0 >= 9 * cpt) {  // a split-K slice that starts inside the skip segment
+    st_tap = 9; st_cc = kt0 - 9 * cpt;
+    if (st_cc >= cpt1) { st_tap = 10; st_cc -= cpt1; }
+  }
   int st_kw = 0, st_g = 0;  // HX: (st_tap = kh, st_cc = chunk, st_kw) of the next tile to stage; st_g = its (kh, chunk) group number
   auto conv_tap_ptrs = [&](int tap) {
     if constexpr (HX) {  // tap = kh: source offsets of the halo tile rows
@@ -235,6 +254,24 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         const unsigned b = a_pk[i] >> 22;
         const bool ok = b != 1023u && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
         a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + iy) * p.Ws + ix) * (unsigned)p.lda0 + cch * 8) * 2 : PAD_OFF;
+      }
+      return;
+    }
+    if (SK && tap >= 9) {  // fused 1x1 skip: the output pixel itself in A1 / A2 (stride 1, same resolution: checked by the host)
+      const unsigned ld = k_lda1 + (k_dlda2 & (tap == 9 ? 0u : ~0u));
+#pragma unroll
+      for (int i = 0; i < A_PW; i++) {
+        const int iy = (int)(a_pk[i] & 2047u) - 1 + p.pad, ix = (int)((a_pk[i] >> 11) & 2047u) - 1 + p.pad;
+        const unsigned b = a_pk[i] >> 22;
+        a_off1[i] = b != 1023u ? ((unsigned)(((int)b * p.Hs + iy) * p.Ws + ix) * ld + cch * 8) * 2 : PAD_OFF;
+      }
+#pragma unroll
+      for (int i = 0; i < W_PW; i++) {  // the skip weights have their own row pitch
+        const int rho = (iw + i * NI) * 8 + lrow;
+        const int wq = rho / BNw, rr = rho - wq * BNw, fn = rr >> 4, ii = rr & 15;
+        int n = n0 + wq * BNw + (ii >> 2) * (4 * FN) + fn * 4 + (ii & 3);
+        if (n >= p.N) n = p.N - 1;
+        w_off[i] = ((unsigned)n * k_ldw1 + cch * 8) * 2;
       }
       return;
     }
@@ -262,15 +299,26 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
     const int nrec = live ? 0x7ffffff0 : 0;
     const int k0 = (kt0 + kt) * 64;
     t.second = !CONV && k0 >= p.K0;  // wave-uniform: second concat source
+    const bool skip = SK && st_tap >= 9;  // wave-uniform
     if constexpr (CONV) {
-      t.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(A0), 0, nrec, 0x00020000);
+      if constexpr (SK) {
+        const long long da = (dA1 & (st_tap == 9 ? -1LL : 0LL)) + (dA2 & (st_tap >= 10 ? -1LL : 0LL));
+        t.ra = __builtin_amdgcn_make_buffer_rsrc((half_t*)((uintptr_t)A0 + (uintptr_t)da), 0, nrec, 0x00020000);
+      } else {
+        t.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(A0), 0, nrec, 0x00020000);
+      }
       t.a_soff = st_cc * 128;
     } else {
       t.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(t.second ? A1 : A0), 0, nrec, 0x00020000);
       t.a_soff = (t.second ? k0 - p.K0 : k0) * 2;
     }
-    t.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Wt), 0, nrec, 0x00020000);
-    t.w_soff = k0 * 2;
+    if constexpr (SK) {
+      t.rw = __builtin_amdgcn_make_buffer_rsrc((half_t*)((uintptr_t)Wt + (uintptr_t)(dW1 & (skip ? -1LL : 0LL))), 0, nrec, 0x00020000);
+      t.w_soff = skip ? ((st_tap == 9 ? 0u : k_cin1) + (unsigned)st_cc * 64) * 2 : (unsigned)k0 * 2;
+    } else {
+      t.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Wt), 0, nrec, 0x00020000);
+      t.w_soff = k0 * 2;
+    }
     t.a_on = true; t.abuf = 0;
     if constexpr (HX) {
       t.w_soff = (unsigned)((st_tap * 3 + st_kw) * p.Cin + st_cc * 64) * 2;
@@ -308,10 +356,11 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         }
       }
     } else if constexpr (CONV) {
-      if (++st_cc == cpt) {
+      const int lim = SK ? cpt + ((cpt1 - cpt) & (st_tap == 9 ? -1 : 0)) + ((cpt2 - cpt) & (st_tap >= 10 ? -1 : 0)) : cpt;
+      if (++st_cc == lim) {
         st_cc = 0;
         ++st_tap;
-        if (st_tap < 9) conv_tap_ptrs(st_tap);
+        if (st_tap < ntaps) conv_tap_ptrs(st_tap);
       }
     }
   };
@@ -980,11 +1029,12 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false, bool HX = false, int LW = 0>
+template <int WGM, int WGN, int FM, int FN, bool CONV, int NS = 2, bool PP = false, int CV = 0, int LW = 0>
 static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
+  constexpr bool HX = CV == 1;
   constexpr int LDS = HX ? NS * BN * 128 + 2 * (BM / 8 + 1) * 1024 : NS * (BM + BN) * 128;
-  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP, HX, LW>;
+  auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP, CV, LW>;
   static unsigned long long attr_set = 0;  // per DEVICE: the attribute is stored per device (one bit each)
   if (!((attr_set >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1042,46 +1092,50 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 constexpr int N_GEMM_CFG = 56;
 static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
-template <bool CONV>
+// SKV = 2 for a conv3x3 with a fused 1x1 skip source (GemmK::Cin1 > 0), else 0: the plain kernels carry none of its scalar state
+template <bool CONV, int SKV = 0>
 static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
+  if constexpr (CONV && SKV == 0) {
+    if (k.Cin1 > 0) return launch_by_id<CONV, 2>(ctx, k, batch, id);
+  }
   switch (id) {
-    case 0: return launch_cfg<2, 2, 4, 5, CONV, 2>(ctx, k, batch);
-    case 1: return launch_cfg<2, 2, 2, 5, CONV, 2>(ctx, k, batch);
-    case 2: return launch_cfg<2, 2, 4, 4, CONV, 2>(ctx, k, batch);
-    case 3: return launch_cfg<2, 2, 2, 4, CONV, 2>(ctx, k, batch);
-    case 4: return launch_cfg<4, 1, 2, 1, CONV, 2>(ctx, k, batch);
-    case 5: return launch_cfg<2, 2, 4, 5, CONV, 3>(ctx, k, batch);
-    case 6: return launch_cfg<2, 2, 2, 5, CONV, 4>(ctx, k, batch);
-    case 7: return launch_cfg<2, 2, 2, 5, CONV, 3>(ctx, k, batch);
-    case 8: return launch_cfg<2, 2, 4, 4, CONV, 3>(ctx, k, batch);
-    case 9: return launch_cfg<2, 2, 2, 4, CONV, 4>(ctx, k, batch);
-    case 10: return launch_cfg<2, 2, 2, 4, CONV, 3>(ctx, k, batch);
-    case 11: return launch_cfg<4, 2, 4, 5, CONV, 3>(ctx, k, batch);
-    case 13: return launch_cfg<4, 2, 4, 4, CONV, 3>(ctx, k, batch);
+    case 0: return launch_cfg<2, 2, 4, 5, CONV, 2, false, SKV>(ctx, k, batch);
+    case 1: return launch_cfg<2, 2, 2, 5, CONV, 2, false, SKV>(ctx, k, batch);
+    case 2: return launch_cfg<2, 2, 4, 4, CONV, 2, false, SKV>(ctx, k, batch);
+    case 3: return launch_cfg<2, 2, 2, 4, CONV, 2, false, SKV>(ctx, k, batch);
+    case 4: return launch_cfg<4, 1, 2, 1, CONV, 2, false, SKV>(ctx, k, batch);
+    case 5: return launch_cfg<2, 2, 4, 5, CONV, 3, false, SKV>(ctx, k, batch);
+    case 6: return launch_cfg<2, 2, 2, 5, CONV, 4, false, SKV>(ctx, k, batch);
+    case 7: return launch_cfg<2, 2, 2, 5, CONV, 3, false, SKV>(ctx, k, batch);
+    case 8: return launch_cfg<2, 2, 4, 4, CONV, 3, false, SKV>(ctx, k, batch);
+    case 9: return launch_cfg<2, 2, 2, 4, CONV, 4, false, SKV>(ctx, k, batch);
+    case 10: return launch_cfg<2, 2, 2, 4, CONV, 3, false, SKV>(ctx, k, batch);
+    case 11: return launch_cfg<4, 2, 4, 5, CONV, 3, false, SKV>(ctx, k, batch);
+    case 13: return launch_cfg<4, 2, 4, 4, CONV, 3, false, SKV>(ctx, k, batch);
     // loader-wave variants (LW = 4): 40 + the id of the 4-wave one-block-per-CU configuration they extend, 51 = cfg 11 + loaders
-    case 45: return launch_cfg<2, 2, 4, 5, CONV, 3, false, false, 4>(ctx, k, batch);
-    case 46: return launch_cfg<2, 2, 2, 5, CONV, 4, false, false, 4>(ctx, k, batch);
-    case 47: return launch_cfg<2, 2, 2, 5, CONV, 3, false, false, 4>(ctx, k, batch);
-    case 48: return launch_cfg<2, 2, 4, 4, CONV, 3, false, false, 4>(ctx, k, batch);
-    case 49: return launch_cfg<2, 2, 2, 4, CONV, 4, false, false, 4>(ctx, k, batch);
-    case 50: return launch_cfg<2, 2, 2, 4, CONV, 3, false, false, 4>(ctx, k, batch);
-    case 51: return launch_cfg<4, 2, 4, 5, CONV, 3, false, false, 4>(ctx, k, batch);
-    case 53: return launch_cfg<4, 2, 4, 4, CONV, 3, false, false, 4>(ctx, k, batch);
-    case 54: return launch_cfg<4, 2, 2, 5, CONV, 3, false, false, 4>(ctx, k, batch);  // 128x160, staggered: 8 compute waves of 32x80
-    case 55: return launch_cfg<4, 2, 2, 4, CONV, 3, false, false, 4>(ctx, k, batch);  // 128x128
+    case 45: return launch_cfg<2, 2, 4, 5, CONV, 3, false, SKV, 4>(ctx, k, batch);
+    case 46: return launch_cfg<2, 2, 2, 5, CONV, 4, false, SKV, 4>(ctx, k, batch);
+    case 47: return launch_cfg<2, 2, 2, 5, CONV, 3, false, SKV, 4>(ctx, k, batch);
+    case 48: return launch_cfg<2, 2, 4, 4, CONV, 3, false, SKV, 4>(ctx, k, batch);
+    case 49: return launch_cfg<2, 2, 2, 4, CONV, 4, false, SKV, 4>(ctx, k, batch);
+    case 50: return launch_cfg<2, 2, 2, 4, CONV, 3, false, SKV, 4>(ctx, k, batch);
+    case 51: return launch_cfg<4, 2, 4, 5, CONV, 3, false, SKV, 4>(ctx, k, batch);
+    case 53: return launch_cfg<4, 2, 4, 4, CONV, 3, false, SKV, 4>(ctx, k, batch);
+    case 54: return launch_cfg<4, 2, 2, 5, CONV, 3, false, SKV, 4>(ctx, k, batch);  // 128x160, staggered: 8 compute waves of 32x80
+    case 55: return launch_cfg<4, 2, 2, 4, CONV, 3, false, SKV, 4>(ctx, k, batch);  // 128x128
     // halo-x variants of 0 and 2 (conv3x3, stride 1: hx_eligible)
-    case 30: if constexpr (CONV) return launch_cfg<2, 2, 4, 5, CONV, 2, false, true>(ctx, k, batch); else break;
-    case 32: if constexpr (CONV) return launch_cfg<2, 2, 4, 4, CONV, 2, false, true>(ctx, k, batch); else break;
+    case 30: if constexpr (CONV && SKV == 0) return launch_cfg<2, 2, 4, 5, CONV, 2, false, 1>(ctx, k, batch); else break;
+    case 32: if constexpr (CONV && SKV == 0) return launch_cfg<2, 2, 4, 4, CONV, 2, false, 1>(ctx, k, batch); else break;
 #ifdef TSD_GEMM_EXPERIMENTAL  // measured, not faster: built only to reproduce those numbers
-    case 12: return launch_cfg<4, 2, 4, 5, CONV, 2>(ctx, k, batch);
-    case 14: return launch_cfg<2, 2, 8, 5, CONV, 3>(ctx, k, batch);
-    case 15: return launch_cfg<2, 2, 8, 5, CONV, 2>(ctx, k, batch);
-    case 16: return launch_cfg<4, 2, 4, 5, CONV, 3, true>(ctx, k, batch);  // 256x160 ping-pong
-    case 17: return launch_cfg<4, 2, 2, 5, CONV, 3, true>(ctx, k, batch);  // 128x160 ping-pong
-    case 18: return launch_cfg<4, 2, 4, 4, CONV, 3, true>(ctx, k, batch);  // 256x128 ping-pong
-    case 19: return launch_cfg<4, 2, 2, 4, CONV, 3, true>(ctx, k, batch);  // 128x128 ping-pong
-    case 20: return launch_cfg<2, 2, 2, 5, CONV, 5>(ctx, k, batch);  // 64x160, 5-slot ring: slower than 4 slots (667 vs 821 TF)
-    case 21: return launch_cfg<2, 2, 2, 4, CONV, 6>(ctx, k, batch);  // 64x128, 6-slot ring
+    case 12: return launch_cfg<4, 2, 4, 5, CONV, 2, false, SKV>(ctx, k, batch);
+    case 14: return launch_cfg<2, 2, 8, 5, CONV, 3, false, SKV>(ctx, k, batch);
+    case 15: return launch_cfg<2, 2, 8, 5, CONV, 2, false, SKV>(ctx, k, batch);
+    case 16: return launch_cfg<4, 2, 4, 5, CONV, 3, true, SKV>(ctx, k, batch);  // 256x160 ping-pong
+    case 17: return launch_cfg<4, 2, 2, 5, CONV, 3, true, SKV>(ctx, k, batch);  // 128x160 ping-pong
+    case 18: return launch_cfg<4, 2, 4, 4, CONV, 3, true, SKV>(ctx, k, batch);  // 256x128 ping-pong
+    case 19: return launch_cfg<4, 2, 2, 4, CONV, 3, true, SKV>(ctx, k, batch);  // 128x128 ping-pong
+    case 20: return launch_cfg<2, 2, 2, 5, CONV, 5, false, SKV>(ctx, k, batch);  // 64x160, 5-slot ring: slower than 4 slots (667 vs 821 TF)
+    case 21: return launch_cfg<2, 2, 2, 4, CONV, 6, false, SKV>(ctx, k, batch);  // 64x128, 6-slot ring
 #endif
     default: break;
   }
@@ -1101,7 +1155,7 @@ static int hx_mode() {
 static bool hx_shape_ok(const GemmK& k);
 static bool hx_eligible(const GemmK& k) { return hx_mode() > 0 && hx_shape_ok(k); }
 static bool hx_shape_ok(const GemmK& k) {
-  return k.stride == 1 && !k.ups && k.pad == 1 && k.splitk <= 1 && k.Hs == k.Ho && k.Ws == k.Wo && k.Cin % 64 == 0 &&
+  return k.stride == 1 && !k.ups && k.pad == 1 && k.splitk <= 1 && !k.Cin1 && k.Hs == k.Ho && k.Ws == k.Wo && k.Cin % 64 == 0 &&
          (k.Wo == 64 || k.Wo % 128 == 0) && ((long long)k.Ho * k.Wo) % 128 == 0 && k.M % 128 == 0 && k.Ho < 2040 && k.Wo < 2040;
 }
 
@@ -1389,7 +1443,12 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   if (a.conv ? (a.epi & (EPI_GEGLU | EPI_BIAS_M)) : (a.epi & (EPI_ROWVEC | EPI_RES_UPS)))
     TSD_FAIL(TSD_E_ARG, "gemm: epilogue flags 0x%x are not available for %s", a.epi, a.conv ? "conv3x3" : "dense GEMMs");
   if (a.conv) {
-    if (a.Cin % 64 || a.K != 9 * a.Cin) TSD_FAIL(TSD_E_SHAPE, "conv3x3: Cin=%d K=%d", a.Cin, a.K);
+    if (a.Cin % 64 || a.K != 9 * a.Cin + a.Cin1 + a.Cin2) TSD_FAIL(TSD_E_SHAPE, "conv3x3: Cin=%d K=%d", a.Cin, a.K);
+    if (a.Cin1 || a.Cin2) {  // fused 1x1 skip (residual block): same resolution as the output, whole 64-channel chunks
+      if (a.Cin1 <= 0 || a.Cin1 % 64 || a.Cin2 % 64 || !a.A1 || (a.Cin2 && !a.A2) || !a.Wt1 || a.stride != 1 || a.ups || a.Ho != a.Hs ||
+          a.Wo != a.Ws || a.lda1 < a.Cin1 || (a.Cin2 && a.lda2 < a.Cin2) || a.ldw1 < a.Cin1 + a.Cin2)
+        TSD_FAIL(TSD_E_ARG, "conv3x3: fused skip source (%d + %d channels) does not fit this convolution", a.Cin1, a.Cin2);
+    }
     if (a.batch != 1) TSD_FAIL(TSD_E_ARG, "conv3x3: batch is folded into M");
   } else {
     if (a.K0 % 64) TSD_FAIL(TSD_E_SHAPE, "gemm: concat split K0=%d must be a multiple of 64", a.K0);
@@ -1399,7 +1458,8 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     const long long a_bytes = a.conv ? 2LL * (a.M / (a.Ho * a.Wo)) * a.Hs * a.Ws * a.lda0
                                      : 2LL * ((long long)(a.M - 1) * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) + a.K);
     const long long w_bytes = 2LL * ((long long)(a.N - 1) * a.ldw + a.K);
-    if (a_bytes > lim || w_bytes > lim)
+    const long long s_bytes = a.conv && a.Cin1 ? 2LL * (a.M / (a.Ho * a.Wo)) * a.Hs * a.Ws * (a.lda1 > a.lda2 ? a.lda1 : a.lda2) : 0;
+    if (a_bytes > lim || w_bytes > lim || s_bytes > lim)
       TSD_FAIL(TSD_E_SHAPE, "gemm: operand slice of %lld / %lld bytes exceeds the 2 GiB addressing window", a_bytes, w_bytes);
   }
   if (a.epi & EPI_GNSTATS) {
@@ -1427,6 +1487,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.rowvec_ld = a.rowvec_ld; k.rows_per_batch = a.rows_per_batch > 0 ? a.rows_per_batch : 1;
   k.M = a.M; k.N = a.N; k.K = a.K;
   k.Hs = a.Hs; k.Ws = a.Ws; k.Ho = a.Ho; k.Wo = a.Wo; k.Cin = a.Cin; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
+  k.A2 = a.A2; k.Wt1 = a.Wt1; k.lda2 = a.lda2; k.Cin1 = a.conv ? a.Cin1 : 0; k.Cin2 = a.conv ? a.Cin2 : 0; k.ldw1 = a.ldw1;
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;

@@ -127,6 +127,31 @@ def test_attention_second_reference_keeps_self_peaked_rows_in_the_optimistic_pas
     assert_close(y1, ref, c.tol, c.tol_max, what="self-peaked scores, own-block reference (optimistic pass)")
 
 
+@pytest.mark.parametrize("name", ["unet_res_320_640", "unet_res_640_1280_16", "unet_res_2560_1280_8", "vae_res_256_128"])
+def test_fused_skip_conv_equals_separate_skip_gemm(gpu_ctx, tsd_mod, name):
+    """`conv1x1(x) + conv3x3(h)` of a residual block (diffusion.mojo:70-72, vae.mojo:65-67): the 1x1 convolution as extra K of the
+    3x3 one (default) against the separate GEMM + residual add.  Not bitwise - the fused form keeps the skip term in the fp32
+    accumulator instead of rounding it to fp16 first - so both are held to the oracle and to each other."""
+    from tsd._lib import lib
+    from util import rel_l2
+    L = lib()
+    c = CASES[name]
+    i = c.build()
+    ref = np.asarray(c.oracle(i), dtype=np.float32)
+    prev = L.tsd_debug_set_res_fuse_skip(0)
+    try:
+        y0 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+        L.tsd_debug_set_res_fuse_skip(1)
+        y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+    finally:
+        L.tsd_debug_set_res_fuse_skip(prev)
+    assert_close(y0, ref, c.tol, c.tol_max, what=f"{name}, separate skip GEMM")
+    assert_close(y1, ref, c.tol, c.tol_max, what=f"{name}, skip fused into conv2")
+    d = rel_l2(y1, y0)
+    print(f"[parity] {name}: fused vs separate skip rel_l2={d:.3e}")
+    assert 0.0 < d <= c.tol, d  # two different paths (d > 0) that agree
+
+
 def test_mfma_sustained_probe_reports_a_plausible_ceiling(gpu_ctx):
     """tsd_debug_mfma_sustained: register-resident fp16 MFMA loop; the figure bench.py prints next to the nominal 2.5 PF."""
     import ctypes as C
