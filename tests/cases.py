@@ -430,6 +430,7 @@ _unet_res_case("unet_res_320_320", 320, 320, 8)
 _unet_res_case("unet_res_320_640", 320, 640, 8)
 _unet_res_case("unet_res_dead_concat", 640, 320, 8, Cx=960)     # layer20: declared 640 of 960 channels (App.A D11)
 _unet_res_case("unet_res_640_1280_16", 640, 1280, 16)           # 16x16 level: 2-way split-K conv2 with the fused 1x1 skip segment
+_unet_res_case("unet_res_ragged_128_192", 128, 192, 12)         # M = 144, N = 192: partial tiles in both directions through the fused skip
 _unet_res_case("unet_res_2560_1280_8", 2560, 1280, 8)           # 8x8 level: 8 K slices, the last one starts inside the skip segment
 
 

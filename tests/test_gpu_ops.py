@@ -127,7 +127,7 @@ def test_attention_second_reference_keeps_self_peaked_rows_in_the_optimistic_pas
     assert_close(y1, ref, c.tol, c.tol_max, what="self-peaked scores, own-block reference (optimistic pass)")
 
 
-@pytest.mark.parametrize("name", ["unet_res_320_640", "unet_res_640_1280_16", "unet_res_2560_1280_8", "vae_res_256_128"])
+@pytest.mark.parametrize("name", ["unet_res_320_640", "unet_res_640_1280_16", "unet_res_2560_1280_8", "unet_res_ragged_128_192", "vae_res_256_128"])
 def test_fused_skip_conv_equals_separate_skip_gemm(gpu_ctx, tsd_mod, name):
     """`conv1x1(x) + conv3x3(h)` of a residual block (diffusion.mojo:70-72, vae.mojo:65-67): the 1x1 convolution as extra K of the
     3x3 one (default) against the separate GEMM + residual add.  Not bitwise - the fused form keeps the skip term in the fp32
