@@ -1201,7 +1201,12 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   static const int min_k = getenv("TSD_GEMM_SPLITK_MINK") ? atoi(getenv("TSD_GEMM_SPLITK_MINK")) : 4096;
   static const int max_tiles = getenv("TSD_GEMM_SPLITK_TILES") ? atoi(getenv("TSD_GEMM_SPLITK_TILES")) : 256;
   static const int small_ways = getenv("TSD_GEMM_SPLITK_SMALL") ? atoi(getenv("TSD_GEMM_SPLITK_SMALL")) : 8;
-  if (!on || batch != 1 || N <= 16 || rps <= 0 || rps > 256) return 1;
+  // Round 3 (late): two more layer classes that left half the chip idle at batch 8 -
+  //  * rps <= 256 with at most 4 tile columns (the 32x32 -> 16x16 downsampling conv, N = 640, K = 5760: 64 tiles): 4 slices;
+  //  * rps <= 1024 with N * rps <= 320 * 1024 (the 64x64 -> 32x32 downsampling conv, N = 320, K = 2880: 128 tiles): 2 slices.
+  static const int wide = getenv("TSD_GEMM_SPLITK_WIDE") ? atoi(getenv("TSD_GEMM_SPLITK_WIDE")) : 1;
+  const bool mid = wide && rps > 256 && rps <= 1024 && (long long)N * rps <= 320LL * 1024 && K >= 2880;
+  if (!on || batch != 1 || N <= 16 || rps <= 0 || (rps > 256 && !mid)) return 1;
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
   int ways = 1, BM = 128;
@@ -1214,13 +1219,17 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   } else {
     static const int big_ways = getenv("TSD_GEMM_SPLITK_BIG") ? atoi(getenv("TSD_GEMM_SPLITK_BIG")) : 2;
     ways = K >= 8192 ? big_ways : (K >= min_k ? 2 : 1);
+    if (wide && ways == 2 && ceil_div(N, BN) <= 4) ways = 4;
+    if (mid) ways = 2;
     if (cfg) *cfg = n160 ? 5 : 8;
   }
   // Eligibility looks at N only (8 | N-tiles keeps a tile's slices on one XCD for any M): a condition on the tile
   // count would make the split - and with it the fp32 summation tree - depend on the batch.  The two M-dependent
   // guards below cannot trigger inside the API's limits (B <= 16 with rps <= 256 gives at most 256 tiles).
+  // (round 3: 8 | tiles of one sample does the same for the layers with fewer tile columns)
   const int tiles_n = ceil_div(N, BN), tiles = ceil_div(M, BM) * tiles_n;
-  if (ways == 1 || tiles_n % 8 || tiles > 2 * max_tiles || (ways - 1) * tiles > 4095) return 1;
+  const bool xcd_ok = tiles_n % 8 == 0 || (wide && rps % BM == 0 && (tiles_n * (rps / BM)) % 8 == 0);
+  if (ways == 1 || !xcd_ok || tiles > 2 * max_tiles || (ways - 1) * tiles > 4095) return 1;
   return ways;
 }
 static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
