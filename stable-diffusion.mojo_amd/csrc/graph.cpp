@@ -386,8 +386,13 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
                               u.tproj.N));
   const int tld = u.tproj.N;
   // ---- input ----
+  // `Conv2D(4, 320, 3)` (diffusion.mojo:236): the latent's 4 channels padded to a 64-channel NHWC tensor made the implicit GEMM walk
+  // nine K tiles with 4 of 64 columns live; gathered to im2col rows at the boundary (36 of 64 columns live) it is ONE K tile
+  static const int im2col_on = getenv("TSD_CONV_IN_IM2COL") ? atoi(getenv("TSD_CONV_IN_IM2COL")) : 1;
+  const bool in_im2col = im2col_on && u.conv_in_im2col && u.conv1.I == 4;
   Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
-  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
+  if (in_im2col) TSD_TRY(launch_chw_f32_to_im2col3x3_f16(ctx, latents_chw, B, 4, L, L, x0.p));
+  else TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
   Act a[24];
   // every layer output feeds a GroupNorm (the next block's first norm: 32 groups; the output layer's: 320), so it is
   // allocated with room for the statistics its producer's epilogue emits
@@ -429,7 +434,9 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   };
   // encoders (diffusion.mojo:236-250)
   TSD_TRY(alloc_out(1, L, 320));
-  TSD_TRY(g_conv3x3(ctx, x0, u.conv1, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[1].p, a[1].ld, &a[1]));
+  if (in_im2col) TSD_TRY(g_linear(ctx, cat1(x0), (int64_t)B * L * L, u.conv_in_im2col, 64, u.conv1.Opad, 64, u.conv1.b, nullptr, 0, 0, a[1].p,
+                                  a[1].ld, &a[1], L * L));
+  else TSD_TRY(g_conv3x3(ctx, x0, u.conv1, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, a[1].p, a[1].ld, &a[1]));
   TSD_TRY(res(2, cat1(a[1]), L, 0));
   TSD_TRY(attn(3));
   TSD_TRY(alloc_out(4, L1, 320));
@@ -482,8 +489,12 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
   TSD_TRY(launch_small_linear(ctx, time, B, 1280, 1280, u.tproj.w, u.tproj.Kpad, u.tproj.b, u.tproj.N, 1, tvec,
                               u.tproj.N));
   const int tld = u.tproj.N;
+  static const int im2col_on = getenv("TSD_CONV_IN_IM2COL") ? atoi(getenv("TSD_CONV_IN_IM2COL")) : 1;
+  const bool in_im2col = im2col_on && u.conv_in_im2col && !u.conv.empty() && u.conv[0].I == 4 && SD15_STEPS[0].l.kind == L_CONV &&
+                         SD15_STEPS[0].l.d == 1;  // as in g_unet_forward: the 4-channel input convolution as one im2col K tile
   Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
-  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
+  if (in_im2col) TSD_TRY(launch_chw_f32_to_im2col3x3_f16(ctx, latents_chw, B, 4, L, L, x0.p));
+  else TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
   // context K and V^T of all sixteen attention blocks in two GEMMs
   const int CK = u.kproj_all.N;
   half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
@@ -511,6 +522,10 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
     if (l.kind == L_CONV) {
       const int side = cur.H / l.d;
       y = act_alloc_gn(ctx, B, side, side, l.b, next_groups); CHECK_ALLOC(y.p);
+      if (i == 0 && in_im2col)
+        TSD_TRY(g_linear(ctx, cat1(cur), (int64_t)B * L * L, u.conv_in_im2col, 64, u.conv[0].Opad, 64, u.conv[0].b, nullptr, 0, 0, y.p, y.ld,
+                         &y, L * L));
+      else
       TSD_TRY(g_conv3x3(ctx, cur, u.conv[i], l.d, 1, 1, 0, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
     } else if (l.kind == L_UPCONV) {
       y = act_alloc_gn(ctx, B, cur.H * 2, cur.W * 2, l.b, next_groups); CHECK_ALLOC(y.p);

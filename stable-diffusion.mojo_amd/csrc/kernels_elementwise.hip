@@ -45,6 +45,51 @@ int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int
   return TSD_OK;
 }
 
+// im2col rows of a 3x3 / stride 1 / pad 1 convolution over a C-channel (C <= 7) fp32 CHW image: one thread per 16-B chunk of a
+// 64-wide row; column t*C + c = tap t = (kh, kw), channel c.  The 4-channel latent padded to 64 channels cost the input
+// convolution nine K tiles of which 1/16 carried data (diffusion.mojo:236 `Conv2D(4, 320, 3)`).
+__global__ void k_chw_to_im2col3x3(const float* __restrict__ src, int C, int H, int W, half_t* __restrict__ dst, int64_t total_chunks) {
+  const int HW = H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i & 7);
+    const int64_t pixg = i >> 3;
+    const int64_t b = pixg / HW;
+    const int pix = (int)(pixg - b * HW), y = pix / W, x = pix - y * W;
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int col = cc * 8 + j, t = col / C, c = col - t * C;
+      const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+      const bool ok = t < 9 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      v[j] = ok ? (half_t)src[(b * C + c) * HW + iy * W + ix] : (half_t)0.f;
+    }
+    *(h8*)(dst + pixg * 64 + cc * 8) = v;
+  }
+}
+int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst) {
+  if (C <= 0 || 9 * C > 64) TSD_FAIL(TSD_E_SHAPE, "im2col: %d channels do not fit a 64-wide row", C);
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)B * H * W * 8;
+  ProfScope prof(ctx, KC_ELEMENTWISE);
+  hipLaunchKernelGGL(k_chw_to_im2col3x3, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H, W, dst, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+// packed conv3x3 weights [O][9][Ipad] fp16 -> [O][64]: column t*C + c = w[o][t][c], zero beyond 9*C
+__global__ void k_pack_im2col_w(const half_t* __restrict__ w, int O, int Ipad, int C, half_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * 64) return;
+  const int o = i >> 6, col = i & 63, t = col / C, c = col - t * C;
+  dst[i] = t < 9 ? w[((int64_t)o * 9 + t) * Ipad + c] : (half_t)0.f;
+}
+int launch_pack_im2col_w(tsd_ctx* ctx, const half_t* w, int O, int Ipad, int C, half_t* dst) {
+  if (C <= 0 || 9 * C > 64 || C > Ipad) TSD_FAIL(TSD_E_SHAPE, "im2col weights: %d channels", C);
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_pack_im2col_w, dim3((O * 64 + 255) / 256), dim3(256), 0, ctx->stream, w, O, Ipad, C, dst);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
 template <class T>
 __global__ void k_nhwc_to_chw(const T* __restrict__ src, int C, int HW, int ld, float* __restrict__ dst,
                               int64_t total) {

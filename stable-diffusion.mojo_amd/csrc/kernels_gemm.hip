@@ -1079,7 +1079,8 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //   1   64x160   2       56 KiB   mid-M
 //   2  128x128   2       64 KiB   VAE widths
 //   3   64x128   2       48 KiB
-//   4  128x16    2       36 KiB   N <= 16 (final 320->4, decoder 128->3)
+//   4  128x16    2       36 KiB   N <= 16, many tiles (decoder 128->3)
+//  24   64x16    4       40 KiB   N <= 16, few tiles (UNet 320->4)
 //   5  128x160   3      108 KiB   deep ring, 1 block/CU
 //   6   64x160   4      112 KiB   few-tile problems (M = 2048 level)
 //   7   64x160   3       84 KiB
@@ -1112,6 +1113,8 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
     case 10: return launch_cfg<2, 2, 2, 4, CONV, 3, false, SKV>(ctx, k, batch);
     case 11: return launch_cfg<4, 2, 4, 5, CONV, 3, false, SKV>(ctx, k, batch);
     case 13: return launch_cfg<4, 2, 4, 4, CONV, 3, false, SKV>(ctx, k, batch);
+    // thin tile (N <= 16) with 64 rows and a 4-slot ring: few-tile problems (the UNet's 320 -> 4 output convolution)
+    case 24: return launch_cfg<4, 1, 1, 1, CONV, 4, false, SKV>(ctx, k, batch);
     // loader-wave variants (LW = 4): 40 + the id of the 4-wave one-block-per-CU configuration they extend, 51 = cfg 11 + loaders
     case 45: return launch_cfg<2, 2, 4, 5, CONV, 3, false, SKV, 4>(ctx, k, batch);
     case 46: return launch_cfg<2, 2, 2, 5, CONV, 4, false, SKV, 4>(ctx, k, batch);
@@ -1233,7 +1236,14 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   return ways;
 }
 static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
-  if (N <= 16) return 4;
+  if (N <= 16) {
+    // the UNet's 320 -> 4 output convolution is one 128-row block per CU walking 45 K tiles behind a 2-slot ring: 64-row tiles with
+    // a 4-slot ring (two blocks per CU, three tiles in flight) take 20 us where it took 33 in the step; with thousands of tiles
+    // (the decoder's 128 -> 3 at 512 x 512) the 128-row tile stays ahead (277 vs 329 us).  Bitwise the same results either way.
+    static const int thin = getenv("TSD_GEMM_THIN_CFG") ? atoi(getenv("TSD_GEMM_THIN_CFG")) : 0;
+    if (thin) return thin;
+    return (long long)ceil_div(M, 128) * batch <= 1024 ? 24 : 4;
+  }
   {
     int sk_cfg = 0;
     if (splitk_plan(M, N, K, batch, rps, &sk_cfg) > 1) return sk_cfg;

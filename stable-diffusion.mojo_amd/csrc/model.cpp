@@ -22,6 +22,7 @@ bool attn_head_weights_ok(const AttnW& w) {
 static void model_invalidate_derived(tsd_model* m) {
   m->ready = false;
   for (auto& a : m->unet.attn) { a.tail_stream = nullptr; a.head_stream = nullptr; }
+  m->unet.conv_in_im2col = nullptr;
 }
 
 static size_t packed_bytes(const ParamSpec& p) {
@@ -161,9 +162,13 @@ static int model_build_derived(tsd_model* m) {
   tsd_ctx* ctx = m->ctx;
   std::vector<AttnW*> el;
   for (auto& a : m->unet.attn) if (a.C && (attn_tail_weights_ok(a) || attn_head_weights_ok(a))) el.push_back(&a);
-  if (el.empty()) return TSD_OK;
+  // input convolution (4 latent channels): [Opad][64] im2col weights
+  const ConvW& cin = is_full_unet_kind(m->kind) ? (m->unet.conv.empty() ? m->unet.conv1 : m->unet.conv[0]) : m->unet.conv1;
+  const bool cin_ok = cin.w && cin.k == 3 && cin.I > 0 && 9 * cin.I <= 64 && cin.Ipad == 64;
+  const size_t cin_b = cin_ok ? ((size_t)cin.Opad * 64 * sizeof(half_t) + 255) & ~size_t(255) : 0;
+  if (el.empty() && !cin_ok) return TSD_OK;
   const size_t tail_b = (attn_tail_stream_bytes() + 255) & ~size_t(255), head_b = (attn_head_stream_bytes() + 255) & ~size_t(255);
-  const size_t each = tail_b + head_b, need = each * el.size();
+  const size_t each = tail_b + head_b, need = each * el.size() + cin_b;
   HIP_TRY(hipSetDevice(ctx->device));
   if (m->derived_bytes < need) {
     if (m->derived) HIP_TRY(hipFree(m->derived));
@@ -188,6 +193,11 @@ static int model_build_derived(tsd_model* m) {
       r = launch_attn_head_pack(ctx, a.conv_in.w, a.conv_in.Ipad, a.sa_in.w, a.sa_in.Kpad, hd);
       if (r == TSD_OK) a.head_stream = hd;
     }
+  }
+  if (r == TSD_OK && cin_ok) {
+    half_t* dst = (half_t*)(m->derived + each * el.size());
+    r = launch_pack_im2col_w(ctx, cin.w, cin.Opad, cin.Ipad, cin.I, dst);
+    if (r == TSD_OK) m->unet.conv_in_im2col = dst;
   }
   ctx->arena.planning = was_planning;
   return r;

@@ -85,6 +85,9 @@ struct UNetW {
   LinW tproj;        // concatenated layer3 of the 9 residual blocks: [6720][1280]
   LinW kproj_all, vproj_all;  // concatenated cross-attention k_proj / v_proj of the 9 attention blocks: [6720][768]
   ConvW conv1, conv4, conv7, final_conv;
+  // derived: the input convolution's weights as a [Opad][64] matrix over K = (tap, cin) for cin < 8 (model_check_ready): the 4-channel
+  // latent is gathered to im2col rows at the boundary and the convolution runs as ONE 64-deep K tile instead of nine padded taps
+  const half_t* conv_in_im2col = nullptr;
   std::vector<ResW> res;    // indexed by flat layer position (23 entries, or SD15_N)
   std::vector<AttnW> attn;
   std::vector<ConvW> conv;  // full-size UNet only: input, downsample and upsample convolutions

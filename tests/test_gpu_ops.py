@@ -81,6 +81,18 @@ def test_tile_configurations_are_bitwise_equivalent(gpu_ctx, tsd_mod, conv, B, H
         assert d.value == 0.0 and m.value > 0.0, f"cfg {cfg} differs from cfg {ref}: max|diff| {d.value} (max|ref| {m.value})"
 
 
+@pytest.mark.parametrize("B,H,Cin", [(2, 16, 320), (1, 24, 128), (8, 64, 320)])
+def test_thin_tile_configurations_are_bitwise_equivalent(gpu_ctx, B, H, Cin):
+    """N <= 16 convolutions (the UNet's 320 -> 4 and the decoder's 128 -> 3 output layers): the 64-row / 4-slot tile the dispatcher
+    picks for few-tile problems against the 128-row / 2-slot one - same K order, identical bits."""
+    import ctypes as C
+    from tsd._lib import lib
+    d, m = C.c_float(), C.c_float()
+    r = lib().tsd_debug_gemm_check(gpu_ctx.h, 1, B, H, H, Cin, 4, 1, 0, 24, 4, C.byref(d), C.byref(m))
+    assert r == 0, r
+    assert d.value == 0.0 and m.value > 0.0, (d.value, m.value)
+
+
 def test_attention_exact_pass_runs_only_when_a_row_overflows(gpu_ctx, tsd_mod):
     """kernels_attn.hip runs the softmax optimistically (reference = first key tile's row maximum + 4, in log2 units) and
     repeats a workgroup with the exact running maximum only if an fp16 probability overflowed.  Ordinary inputs must never
