@@ -237,9 +237,16 @@ struct NormAffine {
   const float* b = nullptr;  // [C] (nullptr: zeros)
   int torch_rstd = 1;        // 1: rsqrt(var + eps) ; 0: 1 / (sqrt(var) + eps)
 };
+// Statistics of a GroupNorm as sums of producer-emitted partials of a FINER grouping: norm group g = fine groups
+// [g*comb, (g+1)*comb) of the concatenation (part0: G0 fine groups, part1: G1) - both [B][nslab][G*][2], one slab per 32 rows.
+struct GnComposite {
+  const float* part0 = nullptr; int G0 = 0;
+  const float* part1 = nullptr; int G1 = 0;
+  int nslab = 0, comb = 1;
+};
 int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
                      int silu, half_t* y, int ldy, const float* pre_part = nullptr, int pre_nslab = 0,
-                     const NormAffine* aff = nullptr);
+                     const NormAffine* aff = nullptr, const GnComposite* comp = nullptr);
 int launch_layernorm(tsd_ctx* ctx, const half_t* x, int64_t rows, int C, int ldx, float eps, half_t* y, int ldy,
                      const NormAffine* aff = nullptr);
 

@@ -113,8 +113,19 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   // GN -> SiLU (only the first cin channels are normalised/consumed: App.A D11)
   Act h = act_alloc(ctx, B, Hin, Win, cin); CHECK_ALLOC(h.p);
   const bool x_stats = !(x.p1 && cin > x.C0) && x.gn_part0 && x.gn_groups0 == w.groups && x.C0 == cin;
+  // channel concat (diffusion.mojo:253-270): the norm's groups are sums of whole groups of the two producers' statistics when both
+  // were emitted at one granularity that divides the concat's group size - no statistics pass over the concatenated tensor
+  GnComposite gc;
+  static const int comp_on = getenv("TSD_GN_COMPOSITE") ? atoi(getenv("TSD_GN_COMPOSITE")) : 1;
+  if (comp_on && x.p1 && cin == x.C0 + x.C1 && x.gn_part0 && x.gn_part1 && x.gn_groups0 > 0 && x.gn_groups1 > 0 &&
+      x.gn_nslab0 == x.gn_nslab1 && x.gn_nslab0 > 0 && x.C0 % x.gn_groups0 == 0 && x.C1 % x.gn_groups1 == 0 && cin % w.groups == 0) {
+    const int cf = x.C0 / x.gn_groups0, cpg = cin / w.groups;
+    if (cf == x.C1 / x.gn_groups1 && cpg % cf == 0) {
+      gc.part0 = x.gn_part0; gc.G0 = x.gn_groups0; gc.part1 = x.gn_part1; gc.G1 = x.gn_groups1; gc.nslab = x.gn_nslab0; gc.comb = cpg / cf;
+    }
+  }
   TSD_TRY(launch_groupnorm(ctx, norm_src(x, cin), B, Hin * Win, cin, w.groups, w.eps, 1.f, 1, h.p, h.ld,
-                           x_stats ? x.gn_part0 : nullptr, x.gn_nslab0, w.gn1.w ? &w.gn1 : nullptr));
+                           x_stats ? x.gn_part0 : nullptr, x.gn_nslab0, w.gn1.w ? &w.gn1 : nullptr, gc.part0 ? &gc : nullptr));
   Act t1 = act_alloc_gn(ctx, B, H, W, cout, w.groups); CHECK_ALLOC(t1.p);
   TSD_TRY(g_conv3x3(ctx, h, w.conv1, 1, 1, 1, ups, tvec ? tvec + w.time_off : nullptr, tld, nullptr, 0, false, t1.p, t1.ld, &t1));
   Act h3 = act_alloc(ctx, B, H, W, cout); CHECK_ALLOC(h3.p);
@@ -397,7 +408,9 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   // every layer output feeds a GroupNorm (the next block's first norm: 32 groups; the output layer's: 320), so it is
   // allocated with room for the statistics its producer's epilogue emits
   auto alloc_out = [&](int i, int side, int C) -> int {
-    a[i] = act_alloc_gn(ctx, B, side, side, C, i == 23 ? 320 : 32);
+    // layers 11 and 16 feed GroupNorm(32) over a concat with a narrower skip (1280 + 640, 640 + 320): statistics in the skip's granularity
+    const int groups = i == 23 ? 320 : (i == 11 ? concat_stat_groups(C, 640, 32) : (i == 16 ? concat_stat_groups(C, 320, 32) : 32));
+    a[i] = act_alloc_gn(ctx, B, side, side, C, groups);
     CHECK_ALLOC(a[i].p);
     return TSD_OK;
   };
@@ -518,6 +531,13 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
     const LayerDef& l = st.l;
     // the next consumer of every layer output starts with GroupNorm(32) (the output layer's has 320 groups)
     const int next_groups = i == SD15_N - 1 ? u.final_groups : 32;
+    // a decoder layer whose output meets a narrower skip in the next residual block's concat emits its statistics in the skip's
+    // granularity (concat_stat_groups), so that block's first GroupNorm needs no statistics pass
+    auto stat_groups = [&](int C) -> int {
+      if (i + 1 < SD15_N && SD15_STEPS[i + 1].l.kind == L_RES && (SD15_STEPS[i + 1].flags & U_POP) && !(st.flags & U_PUSH) && !skips.empty())
+        return concat_stat_groups(C, skips.back().C, 32);
+      return next_groups;
+    };
     Act y;
     if (l.kind == L_CONV) {
       const int side = cur.H / l.d;
@@ -528,7 +548,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
       else
       TSD_TRY(g_conv3x3(ctx, cur, u.conv[i], l.d, 1, 1, 0, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
     } else if (l.kind == L_UPCONV) {
-      y = act_alloc_gn(ctx, B, cur.H * 2, cur.W * 2, l.b, next_groups); CHECK_ALLOC(y.p);
+      y = act_alloc_gn(ctx, B, cur.H * 2, cur.W * 2, l.b, stat_groups(l.b)); CHECK_ALLOC(y.p);
       TSD_TRY(g_conv3x3(ctx, cur, u.conv[i], 1, 1, 1, 1, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
     } else if (l.kind == L_RES) {
       CatSrc src = cat1(cur);
@@ -538,10 +558,10 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
         if (sk.H != cur.H || cur.C + sk.C != l.a) TSD_FAIL(TSD_E_STATE, "full-size UNet: skip mismatch at layer %d", i + 1);
         src = cat2(cur, sk);
       }
-      y = act_alloc_gn(ctx, B, cur.H, cur.W, l.b, next_groups); CHECK_ALLOC(y.p);
+      y = act_alloc_gn(ctx, B, cur.H, cur.W, l.b, stat_groups(l.b)); CHECK_ALLOC(y.p);
       TSD_TRY(g_resblock(ctx, src, B, cur.H, cur.W, 0, u.res[i], tvec, tld, y));
     } else {  // L_ATTN
-      y = act_alloc_gn(ctx, B, cur.H, cur.W, cur.C, next_groups); CHECK_ALLOC(y.p);
+      y = act_alloc_gn(ctx, B, cur.H, cur.W, cur.C, stat_groups(cur.C)); CHECK_ALLOC(y.p);
       const AttnW& w = u.attn[i];
       CtxKV kv;
       kv.K = kc_all + w.kv_off; kv.ldk = CK; kv.sK = (int64_t)Tp * CK;

@@ -8,16 +8,27 @@ struct CatSrc {
   const half_t* p0 = nullptr; int ld0 = 0; int C0 = 0;
   const half_t* p1 = nullptr; int ld1 = 0; int C1 = 0;
   const float* gn_part0 = nullptr; int gn_nslab0 = 0, gn_groups0 = 0;  // producer-emitted GroupNorm statistics of p0
+  const float* gn_part1 = nullptr; int gn_nslab1 = 0, gn_groups1 = 0;  // ... and of p1
 };
 static inline CatSrc cat1(const Act& a) {
   CatSrc c; c.p0 = a.p; c.ld0 = a.ld; c.C0 = a.C;
   c.gn_part0 = a.gn_part; c.gn_nslab0 = a.gn_nslab; c.gn_groups0 = a.gn_groups;
   return c;
 }
+// Groups to emit statistics for on a C0-channel tensor whose consumer is GroupNorm(groups) over concat(it, a C1-channel skip whose
+// own statistics come in C1 / groups-channel groups): the skip's granularity when the concat's groups are whole multiples of it
+// (1280 + 640 -> 60-channel groups = 3 x 20: emit 64 groups of 20), else `groups`
+static inline int concat_stat_groups(int C0, int C1, int groups) {
+  if (C1 <= 0 || C1 % groups || (C0 + C1) % groups) return groups;
+  const int cf = C1 / groups, cpg = (C0 + C1) / groups;
+  return (cpg % cf == 0 && C0 % cf == 0 && C0 / cf <= 256) ? C0 / cf : groups;
+}
 // activation whose producer may emit the statistics of the GroupNorm(groups) that will consume it
 Act act_alloc_gn(tsd_ctx* ctx, int B, int H, int W, int C, int groups);
 static inline CatSrc cat2(const Act& a, const Act& b) {
-  CatSrc c = cat1(a); c.p1 = b.p; c.ld1 = b.ld; c.C1 = b.C; return c;
+  CatSrc c = cat1(a); c.p1 = b.p; c.ld1 = b.ld; c.C1 = b.C;
+  c.gn_part1 = b.gn_part; c.gn_nslab1 = b.gn_nslab; c.gn_groups1 = b.gn_groups;
+  return c;
 }
 
 // y = conv3x3(x) (+bias) (+rowvec per sample) (+residual); `ups`: x is read through a nearest-2x upsample.

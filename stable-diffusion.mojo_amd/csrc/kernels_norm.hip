@@ -26,6 +26,9 @@ struct GnK {
   int ld0, ld1, C0, C, HW, G, cpg;
   int nslab, slab_pixels;
   float* partial;  // [B][nslab][G][2]  (sum, sumsq) per slab
+  // composite statistics (comb > 1): the norm's group g is the sum of `comb` consecutive FINE groups of the producers' partials -
+  // fine groups [0, G0) from `partial` ([B][nslab][G0][2], the first concat source), [G0, G0 + G1) from `partial1`
+  const float* partial1; int G0, G1, comb;
   float* stats;    // [B][G][2]         (mean, gamma/(sigma+eps))
   float eps, gamma;
   int silu;
@@ -123,9 +126,19 @@ __device__ __forceinline__ void gn_finish_groups(const GnK& p, int b, int g0, in
   if (g < p.G)
 #pragma unroll 4
     for (int s = sl; s < p.nslab; s += 8) {
-      const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
-      t1 += (double)o[0];
-      t2 += (double)o[1];
+      if (p.comb <= 1) {
+        const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
+        t1 += (double)o[0];
+        t2 += (double)o[1];
+      } else {
+        for (int k = 0; k < p.comb; k++) {  // fixed order: deterministic
+          const int f = g * p.comb + k;
+          const float* o = f < p.G0 ? p.partial + (((int64_t)b * p.nslab + s) * p.G0 + f) * 2
+                                    : p.partial1 + (((int64_t)b * p.nslab + s) * p.G1 + (f - p.G0)) * 2;
+          t1 += (double)o[0];
+          t2 += (double)o[1];
+        }
+      }
     }
 #pragma unroll
   for (int o = 4; o > 0; o >>= 1) {
@@ -256,7 +269,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnK p) {
 }
 
 int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int groups, float eps, float gamma,
-                     int silu, half_t* y, int ldy, const float* pre_part, int pre_nslab, const NormAffine* aff) {
+                     int silu, half_t* y, int ldy, const float* pre_part, int pre_nslab, const NormAffine* aff,
+                     const GnComposite* comp) {
   if (C % 8 || C % groups || C > 256 * 8 * GN_MAX_CPT)
     TSD_FAIL(TSD_E_SHAPE, "groupnorm: C=%d groups=%d unsupported", C, groups);
   const int C0 = src.x1 ? src.C0 : C;
@@ -271,14 +285,21 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   static const int apply_mult = getenv("TSD_GN_APPLY_MULT") ? atoi(getenv("TSD_GN_APPLY_MULT")) : 2;
   k.apply_pixels = apply_mult * GN_UNROLL * PL;
   // statistics already emitted by the producer's epilogue (EPI_GNSTATS, same [B][nslab][G][2] layout): no partial pass
+  // composite: the statistics are sums of the producers' finer-grained partials (two concat sources, or one source emitted for a
+  // finer grouping) - no statistics pass over the concatenated tensor
+  const bool composite = comp && comp->part0 && comp->comb >= 1 && comp->nslab > 0 && comp->nslab <= 256 &&
+                         (comp->G0 + (comp->part1 ? comp->G1 : 0)) == groups * comp->comb;
+  if (composite) { pre_part = comp->part0; pre_nslab = comp->nslab; }
   const bool have_stats = pre_part != nullptr && pre_nslab > 0;
-  const bool prereduce = have_stats && pre_nslab > 256 && groups <= 256;  // large images (VAE): 64 chunks per sample first
+  const bool prereduce = !composite && have_stats && pre_nslab > 256 && groups <= 256;  // large images (VAE): 64 chunks per sample first
   if (have_stats && !prereduce) { k.partial = const_cast<float*>(pre_part); k.nslab = pre_nslab; }
   else if (prereduce) { k.partial = arena_alloc<float>(ctx, (int64_t)B * 64 * groups * 2); k.nslab = 64; }
   else k.partial = arena_alloc<float>(ctx, (int64_t)B * k.nslab * groups * 2);
   k.stats = arena_alloc<float>(ctx, (int64_t)B * groups * 2);
   if (!k.partial || !k.stats) TSD_FAIL(TSD_E_ALLOC, "groupnorm: workspace exhausted");
   k.eps = eps; k.gamma = gamma; k.silu = silu; k.y = y; k.ldy = ldy;
+  k.partial1 = nullptr; k.G0 = groups; k.G1 = 0; k.comb = 1;
+  if (composite) { k.partial1 = comp->part1; k.G0 = comp->G0; k.G1 = comp->part1 ? comp->G1 : 0; k.comb = comp->G0 == groups && !comp->part1 ? 1 : comp->comb; }
   k.aw = aff ? aff->w : nullptr; k.ab = aff ? aff->b : nullptr; k.torch_rstd = aff ? aff->torch_rstd : 0;
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
