@@ -307,6 +307,11 @@ int tsd_debug_set_attn_diag(int on);
  * inside the second 3x3 convolution as extra K (on = 1, default); on = 0 runs it as its own GEMM + residual add (the round-2 path,
  * kept for A/B and for the equivalence test).  Returns the previous setting. */
 int tsd_debug_set_res_fuse_skip(int on);
+/* Self-attention input projection (helpers/attention.mojo:29-31): q | k (token-major) and V^T (channel-major, what the attention
+ * kernel reads) come from ONE GEMM over in_proj's 3C rows whose tiles beyond column 2C store transposed (on = 1, default; needs
+ * H*W % 32 == 0); on = 0 runs the q/k GEMM and the swapped-operand V^T GEMM as two launches.  Environment: TSD_QKV_FUSE.  Returns
+ * the previous setting. */
+int tsd_debug_set_qkv_fuse(int on);
 /* What this board sustains on the matrix pipe: a register-resident dense fp16 MFMA loop (no LDS, no memory) run for about
  * `ms_target` ms at 4 waves per SIMD; reports the achieved TFLOP/s and the shader clock (GHz) during the run.  The nominal
  * dense peak assumes the boost clock; under matrix-pipe load the board's power limit sets the clock. */

@@ -86,6 +86,19 @@ int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw,
   return launch_gemm(ctx, g);
 }
 
+// q/k/v projection as one GEMM with a transposed tail (GemmArgs::Vt): whole 32-token passes per sample, V columns on a tile boundary
+static int g_qkv_fuse = -1;
+extern "C" int tsd_debug_set_qkv_fuse(int on) {
+  const int prev = g_qkv_fuse < 0 ? 1 : g_qkv_fuse;
+  if (on == 0 || on == 1) g_qkv_fuse = on;
+  return prev;
+}
+static bool qkv_fused_ok(int S, int Sp, int C) {
+  if (g_qkv_fuse < 0) g_qkv_fuse = getenv("TSD_QKV_FUSE") ? atoi(getenv("TSD_QKV_FUSE")) : 1;
+  const int BN = ((3 * C) % 160 == 0) ? 160 : 128;
+  return g_qkv_fuse && S % 32 == 0 && Sp == S && (2 * C) % BN == 0;
+}
+
 static NormSrc norm_src(const CatSrc& x, int C) {
   NormSrc s;
   s.x0 = x.p0; s.ld0 = x.ld0; s.C0 = x.C0;
@@ -200,6 +213,13 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     // ---- self attention (:122-126) ----
     TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C, w.ln[0].w ? &w.ln[0] : nullptr));
     a.p0 = ln; a.ld0 = C; a.C0 = C;
+    if (qkv_fused_ok(S, Sp, C)) {  // q | k token-major and V^T channel-major from ONE GEMM over in_proj's 3C rows (transposed tail)
+      GemmArgs g;
+      g.A0 = ln; g.lda0 = C; g.Wt = w.sa_in.w; g.ldw = w.sa_in.Kpad; g.M = (int)M; g.N = 3 * C; g.K = C;
+      g.C = qk; g.ldc = 2 * C; g.rows_per_sample_hint = S;
+      g.Vt = vt; g.vt_n0 = 2 * C; g.vt_ld = Sp; g.vt_S = S; g.vt_sB = (int64_t)C * Sp;
+      TSD_TRY(launch_gemm(ctx, g));
+    } else {
     TSD_TRY(g_linear(ctx, a, M, w.sa_in.w, w.sa_in.Kpad, 2 * C, C, nullptr, nullptr, 0, 0, qk, 2 * C, nullptr, S));  // q,k
     {  // V^T[b] = W_v . ln_b^T  -> [B][C][S]
       GemmArgs g;
@@ -208,6 +228,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
       g.M = C; g.N = S; g.K = C; g.batch = B;
       g.C = vt; g.ldc = Sp; g.sC = (int64_t)C * Sp;
       TSD_TRY(launch_gemm(ctx, g));
+    }
     }
   }
   a.ld0 = C; a.C0 = C;
@@ -338,6 +359,14 @@ int g_attn_core(tsd_ctx* ctx, const AttnArgs& fa) {
 // q,k (token-major [B*S][2C]) and v^T ([B][C][Sp]) from a fused in_proj (3C, C) (helpers/attention.mojo:29)
 int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& in_proj, half_t* qk, half_t* vt,
                int Sp) {
+  if (qkv_fused_ok(S, Sp, C) && in_proj.Kpad == C) {
+    GemmArgs g;
+    g.A0 = x; g.lda0 = C; g.Wt = in_proj.w; g.ldw = in_proj.Kpad; g.M = B * S; g.N = 3 * C; g.K = in_proj.Kpad;
+    if (in_proj.b) { g.epi = EPI_BIAS_N; g.bias = in_proj.b; }
+    g.C = qk; g.ldc = 2 * C; g.rows_per_sample_hint = S;
+    g.Vt = vt; g.vt_n0 = 2 * C; g.vt_ld = Sp; g.vt_S = S; g.vt_sB = (int64_t)C * Sp;
+    return launch_gemm(ctx, g);
+  }
   CatSrc a; a.p0 = x; a.ld0 = C; a.C0 = C;
   TSD_TRY(g_linear(ctx, a, (int64_t)B * S, in_proj.w, in_proj.Kpad, 2 * C, in_proj.Kpad, in_proj.b, nullptr, 0, 0, qk,
                    2 * C));

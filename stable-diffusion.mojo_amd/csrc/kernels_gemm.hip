@@ -70,6 +70,7 @@ struct GemmK {
   int epi, tiles_n, xcd_n;
   float out_scale;
   float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
+  half_t* vt; long long vt_sB; int vt_n0, vt_ld, vt_S;  // transposed tail: columns >= vt_n0 go to vt[b][n - vt_n0][s] (GemmArgs::Vt)
   float* sk_ws; int* sk_flags; int splitk; int sk_cfg; int sk_epoch;  // split-K (2/4/8 slices): fp32 partial tiles + one arrival flag per (slice, tile); host: tile cfg
 #ifdef TSD_GEMM_TS
   unsigned long long* ts;  // per-block phase timestamps (experiment build only)
@@ -882,6 +883,24 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
           for (int b = 0; b < FN; b++) *(f4*)(row + b * 4) = f4{v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]};
         }
         // same-wave LDS operations complete in order: the row-major reads below see the stores above
+        if (!CONV && p.vt && n0 >= p.vt_n0) {
+          // transposed tail (block-uniform: vt_n0 is a multiple of the tile width): each lane takes one column and eight consecutive
+          // rows of the pass - 16 B of V^T[b][channel][token]; four lanes cover the pass's 32 tokens of a channel (64 B)
+#pragma unroll
+          for (int i = 0; i < (BNw * 4 + 63) / 64; i++) {
+            const int t = lane + 64 * i;
+            const int col = t >> 2, rc = t & 3;
+            const int m = m0 + wm * BMw + pass * 32 + rc * 8;
+            const int n = n0 + wn * BNw + col;
+            if (t >= BNw * 4 || m >= p.M || n >= p.N) continue;
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (half_t)ep[(rc * 8 + j) * EPP + col];
+            const int bsm = m / p.vt_S, srow = m - bsm * p.vt_S;
+            *(h8*)(p.vt + (long long)bsm * p.vt_sB + (long long)(n - p.vt_n0) * p.vt_ld + srow) = o;
+          }
+          continue;
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
           const int t = lane + 64 * i;
@@ -1265,7 +1284,7 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   // (profiles/r03_loader_waves_ab.txt); TSD_GEMM_TUNE bit 2 turns them off.  Results are bitwise those of every other tile.
   if ((tune & 4) && M % 256 == 0) {
     if (n160 && conv && t256 >= 256 && t256 % 256 == 0) return 51;
-    if (n160 && !conv && (t256 == 256 || t256 == 512)) return 51;
+    if (n160 && !conv && (t256 == 256 || t256 == 512 || (t256 >= 192 && t256 < 256))) return 51;  // 192: the 16x16 level's fused q/k/v projection (23 us against 26-33 for the other tiles)
     if (!n160 && conv && N % 128 == 0 && N >= 256 && t256 >= 512) return 53;
   }
   if ((tune & 1) && !conv && n160 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
@@ -1481,6 +1500,12 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     if (a_bytes > lim || w_bytes > lim || s_bytes > lim)
       TSD_FAIL(TSD_E_SHAPE, "gemm: operand slice of %lld / %lld bytes exceeds the 2 GiB addressing window", a_bytes, w_bytes);
   }
+  if (a.Vt) {
+    const int BNt = (a.N % 160 == 0) ? 160 : 128;
+    if (a.conv || a.batch != 1 || (a.epi & ~(EPI_BIAS_N)) || a.N % 8 || a.N <= 16 || a.vt_n0 <= 0 || a.vt_n0 % BNt || a.vt_S <= 0 || a.vt_S % 32 ||
+        a.M % a.vt_S || a.vt_ld < a.vt_S || a.vt_ld % 8 || g_force_cfg >= 0)
+      TSD_FAIL(TSD_E_ARG, "gemm: transposed tail (n0 %d, rows per sample %d, pitch %d) does not fit this launch", a.vt_n0, a.vt_S, a.vt_ld);
+  }
   if (a.epi & EPI_GNSTATS) {
     if ((a.epi & (EPI_GEGLU | EPI_OUT_F32)) || !a.gn_part ||
         a.gn_nslab != gemm_gnstats_slabs(a.M, a.N, a.K, a.batch, a.conv, a.gn_rows_per_sample, a.gn_groups) || a.gn_nslab <= 0)
@@ -1510,6 +1535,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;
+  k.vt = a.Vt; k.vt_sB = a.vt_sB; k.vt_n0 = a.vt_n0; k.vt_ld = a.vt_ld; k.vt_S = a.vt_S;
   k.splitk = splitk ? ways : 1; k.sk_cfg = sk_cfg; k.sk_ws = sk_ws; k.sk_flags = nullptr; k.sk_epoch = 0;
   if (splitk) {
     if (!ctx->sk_flags) {

@@ -114,6 +114,7 @@ def _declare(l):
         "tsd_debug_set_attn_qb": ([i], i),
         "tsd_debug_set_attn_diag": ([i], i),
         "tsd_debug_set_res_fuse_skip": ([i], i),
+        "tsd_debug_set_qkv_fuse": ([i], i),
         "tsd_debug_mfma_sustained": ([vp, C.c_float, fp, fp], i),
         "tsd_debug_gemm_check": ([vp, i, i, i, i, i, i, i, i, i, i, fp, fp], i),
     }

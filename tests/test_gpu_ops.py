@@ -164,6 +164,32 @@ def test_fused_skip_conv_equals_separate_skip_gemm(gpu_ctx, tsd_mod, name):
     assert 0.0 < d <= c.tol, d  # two different paths (d > 0) that agree
 
 
+@pytest.mark.parametrize("name", ["self_attention_d40", "self_attention_d80", "self_attention_d160", "self_attention_vae_1head",
+                                  "unet_attn_8x80", "unet_attn_8x160", "vae_attention_512"])
+def test_fused_qkv_projection_equals_two_launches(gpu_ctx, tsd_mod, name):
+    """helpers/attention.mojo:29-31 `in_proj` + chunk: q | k token-major and V^T channel-major from ONE GEMM whose tiles beyond column
+    2C store transposed (default) against the q/k GEMM + the swapped-operand V^T GEMM.  Same products in the same K order - the
+    outputs are expected to agree bit for bit; both are held to the oracle."""
+    from tsd._lib import lib
+    from util import rel_l2
+    L = lib()
+    c = CASES[name]
+    i = c.build()
+    ref = np.asarray(c.oracle(i), dtype=np.float32)
+    prev = L.tsd_debug_set_qkv_fuse(0)
+    try:
+        y0 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+        L.tsd_debug_set_qkv_fuse(1)
+        y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+    finally:
+        L.tsd_debug_set_qkv_fuse(prev)
+    assert_close(y0, ref, c.tol, c.tol_max, what=f"{name}, two launches")
+    assert_close(y1, ref, c.tol, c.tol_max, what=f"{name}, fused q/k/v projection")
+    d = rel_l2(y1, y0)
+    print(f"[parity] {name}: fused vs separate q/k/v projection rel_l2={d:.3e}")
+    assert d <= 1e-4, d
+
+
 def test_mfma_sustained_probe_reports_a_plausible_ceiling(gpu_ctx):
     """tsd_debug_mfma_sustained: register-resident fp16 MFMA loop; the figure bench.py prints next to the nominal 2.5 PF."""
     import ctypes as C
