@@ -176,7 +176,7 @@ struct GemmArgs {
   float out_scale = 1.f;  // applied to the accumulator before bias/residual
   // Transposed tail (dense GEMMs): output columns n >= vt_n0 are stored channel-major instead - Vt[(m / vt_S) * vt_sB + (n - vt_n0) * vt_ld
   // + m % vt_S] (fp16) - so a fused q/k/v projection leaves q | k token-major in C and V^T [B][C][S] for the attention kernel in
-  // ONE launch (helpers/attention.mojo:29-31).  vt_n0 must be a multiple of the tile width, vt_S (rows per sample) of 32.
+  // ONE launch (helpers/attention.mojo:29-31).  vt_n0 must be a multiple of the tile width, vt_S (rows per sample) of 8.
   half_t* Vt = nullptr; int vt_n0 = 0, vt_ld = 0, vt_S = 0; int64_t vt_sB = 0;
   // EPI_GNSTATS: partial[(b * gn_nslab + slab) * gn_groups + g][2], slab = wave-tile row block within the sample
   float* gn_part = nullptr; int gn_groups = 0, gn_rows_per_sample = 0, gn_nslab = 0;

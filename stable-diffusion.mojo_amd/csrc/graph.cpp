@@ -99,6 +99,14 @@ static bool qkv_fused_ok(int S, int Sp, int C) {
   return g_qkv_fuse && S % 32 == 0 && Sp == S && (2 * C) % BN == 0;
 }
 
+// context K / V^T of all attention blocks from one GEMM: the concatenated v_proj rows follow the k_proj rows in the blob
+static bool ctx_kv_fused_ok(const UNetW& u, int Tp) {
+  if (g_qkv_fuse < 0) g_qkv_fuse = getenv("TSD_QKV_FUSE") ? atoi(getenv("TSD_QKV_FUSE")) : 1;
+  const int CK = u.kproj_all.N;
+  return g_qkv_fuse && Tp % 8 == 0 && CK % 160 == 0 && u.vproj_all.N == CK && u.vproj_all.Kpad == u.kproj_all.Kpad &&
+         u.vproj_all.w == u.kproj_all.w + (int64_t)CK * u.kproj_all.Kpad;
+}
+
 static NormSrc norm_src(const CatSrc& x, int C) {
   NormSrc s;
   s.x0 = x.p0; s.ld0 = x.ld0; s.C0 = x.C0;
@@ -454,7 +462,13 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   const int CK = u.kproj_all.N;
   half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
   half_t* vtc_all = arena_alloc<half_t>(ctx, (int64_t)B * CK * Tp); CHECK_ALLOC(vtc_all);
-  {
+  if (ctx_kv_fused_ok(u, Tp)) {  // k_proj | v_proj rows are adjacent in the blob: one GEMM, the V half stored transposed (GemmArgs::Vt)
+    GemmArgs g;
+    g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
+    g.M = B * Tp; g.N = 2 * CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
+    g.Vt = vtc_all; g.vt_n0 = CK; g.vt_ld = Tp; g.vt_S = Tp; g.vt_sB = (int64_t)CK * Tp;
+    TSD_TRY(launch_gemm(ctx, g));
+  } else {
     GemmArgs g;
     g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
     g.M = B * Tp; g.N = CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
@@ -541,7 +555,13 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
   const int CK = u.kproj_all.N;
   half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
   half_t* vtc_all = arena_alloc<half_t>(ctx, (int64_t)B * CK * Tp); CHECK_ALLOC(vtc_all);
-  {
+  if (ctx_kv_fused_ok(u, Tp)) {  // k_proj | v_proj rows are adjacent in the blob: one GEMM, the V half stored transposed (GemmArgs::Vt)
+    GemmArgs g;
+    g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
+    g.M = B * Tp; g.N = 2 * CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
+    g.Vt = vtc_all; g.vt_n0 = CK; g.vt_ld = Tp; g.vt_S = Tp; g.vt_sB = (int64_t)CK * Tp;
+    TSD_TRY(launch_gemm(ctx, g));
+  } else {
     GemmArgs g;
     g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
     g.M = B * Tp; g.N = CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;

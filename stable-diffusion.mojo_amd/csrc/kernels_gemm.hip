@@ -1502,7 +1502,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   }
   if (a.Vt) {
     const int BNt = (a.N % 160 == 0) ? 160 : 128;
-    if (a.conv || a.batch != 1 || (a.epi & ~(EPI_BIAS_N)) || a.N % 8 || a.N <= 16 || a.vt_n0 <= 0 || a.vt_n0 % BNt || a.vt_S <= 0 || a.vt_S % 32 ||
+    if (a.conv || a.batch != 1 || (a.epi & ~(EPI_BIAS_N)) || a.N % 8 || a.N <= 16 || a.vt_n0 <= 0 || a.vt_n0 % BNt || a.vt_S <= 0 || a.vt_S % 8 ||
         a.M % a.vt_S || a.vt_ld < a.vt_S || a.vt_ld % 8 || g_force_cfg >= 0)
       TSD_FAIL(TSD_E_ARG, "gemm: transposed tail (n0 %d, rows per sample %d, pitch %d) does not fit this launch", a.vt_n0, a.vt_S, a.vt_ld);
   }
