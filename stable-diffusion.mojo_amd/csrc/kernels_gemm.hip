@@ -27,6 +27,7 @@
 //     two-group schedule (tile configurations 51 / 53) - DESIGN.md 4.1 "what a K tile costs".
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -1255,6 +1256,17 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   return ways;
 }
 static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
+  {  // tuning aid: TSD_GEMM_CFG_OVERRIDE="M,N,K:cfg[;M,N,K:cfg...]" forces a tile configuration for exact shapes inside a real step
+    static const char* ov = getenv("TSD_GEMM_CFG_OVERRIDE");
+    if (ov) {
+      for (const char* q = ov; q && *q;) {
+        int m = 0, n = 0, k = 0, c = 0;
+        if (sscanf(q, "%d,%d,%d:%d", &m, &n, &k, &c) == 4 && m == M && n == N && k == K) return c;
+        q = strchr(q, ';');
+        if (q) q++;
+      }
+    }
+  }
   if (N <= 16) {
     // the UNet's 320 -> 4 output convolution is one 128-row block per CU walking 45 K tiles behind a 2-slot ring: 64-row tiles with
     // a 4-slot ring (two blocks per CU, three tiles in flight) take 20 us where it took 33 in the step; with thousands of tiles
@@ -1278,19 +1290,26 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   //  * fewer tiles than that: 64-row tiles with 3 ring slots, 4 when K is long.
   const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
   const long long t256 = (long long)ceil_div(M, 256) * ceil_div(N, BN) * batch;
-  static const int tune = getenv("TSD_GEMM_TUNE") ? atoi(getenv("TSD_GEMM_TUNE")) : 7;  // A/B switch for the two rules below
+  static const int tune = getenv("TSD_GEMM_TUNE") ? atoi(getenv("TSD_GEMM_TUNE")) : 15;  // A/B switch for the two rules below
   // Round 3: the staggered wave-specialised 256-row tiles (51 / 53: 8 compute waves in two groups + 4 loader waves) where a
   // 256-row tiling gives every CU whole tiles - measured -5...-10 % against configurations 0 / 2 / 11 on these shapes
   // (profiles/r03_loader_waves_ab.txt); TSD_GEMM_TUNE bit 2 turns them off.  Results are bitwise those of every other tile.
   if ((tune & 4) && M % 256 == 0) {
     if (n160 && conv && t256 >= 256 && t256 % 256 == 0) return 51;
-    if (n160 && !conv && (t256 == 256 || t256 == 512 || (t256 >= 192 && t256 < 256))) return 51;  // 192: the 16x16 level's fused q/k/v projection (23 us against 26-33 for the other tiles)
+    if (n160 && !conv && (t256 == 256 || t256 == 384 || t256 == 512 || (t256 >= 192 && t256 < 256))) return 51;  // 192: the 16x16 level's fused q/k/v projection (23 us against 26-33 for the other tiles)
     if (!n160 && conv && N % 128 == 0 && N >= 256 && t256 >= 512) return 53;
   }
   if ((tune & 1) && !conv && n160 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
   if (t128 >= 512) return n160 ? 0 : 2;
+  // Round 3 (late), measured INSIDE the step (TSD_GEMM_CFG_OVERRIDE + scripts/instep_sweep.sh; the repeated-launch microbenchmark
+  // keeps the operands in the L2 and ranks these the other way round): dense GEMMs with exactly one 128-row tile per CU run the
+  // staggered 128x160 tile with loader waves (54: 8192x640x640 19.4 -> 17.7 us, 8192x640x2560 42 -> 39.7 us), and the 256-tile
+  // 64-row problems of the 16x16 level the 64x160 tile with loader waves (47: 2048x1280x1280 20.2 -> 19.2 us); TSD_GEMM_TUNE bit 3
+  if ((tune & 8) && !conv && n160 && t128 == 256 && M % 128 == 0 && K < 5760) return 54;
+  if ((tune & 8) && !conv && n160 && N >= 8192 && t128 >= 384) return 0;  // few rows, very wide (context K | V^T: 34 -> 29 us)
   if (t128 >= 192) return (K >= 2560 || !(tune & 2)) ? (n160 ? 5 : 8) : (n160 ? 1 : 3);
   if (K >= 5760) return n160 ? 6 : 9;
+  if ((tune & 8) && !conv && n160 && (long long)ceil_div(M, 64) * ceil_div(N, BN) * batch == 256 && M % 64 == 0) return 47;
   return n160 ? 7 : 10;
 }
 
