@@ -1244,7 +1244,8 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
     ways = K >= 8192 ? big_ways : (K >= min_k ? 2 : 1);
     if (wide && ways == 2 && ceil_div(N, BN) <= 4) ways = 4;
     if (mid) ways = 2;
-    if (cfg) *cfg = n160 ? 5 : 8;
+    static const int sk128 = getenv("TSD_GEMM_SK_CFG") ? atoi(getenv("TSD_GEMM_SK_CFG")) : 5;  // 45: the same tile with loader waves
+    if (cfg) *cfg = n160 ? sk128 : 8;
   }
   // Eligibility looks at N only (8 | N-tiles keeps a tile's slices on one XCD for any M): a condition on the tile
   // count would make the split - and with it the fp32 summation tree - depend on the batch.  The two M-dependent
@@ -1296,10 +1297,10 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   // (profiles/r03_loader_waves_ab.txt); TSD_GEMM_TUNE bit 2 turns them off.  Results are bitwise those of every other tile.
   if ((tune & 4) && M % 256 == 0) {
     if (n160 && conv && t256 >= 256 && t256 % 256 == 0) return 51;
-    if (n160 && !conv && (t256 == 256 || t256 == 384 || t256 == 512 || (t256 >= 192 && t256 < 256))) return 51;  // 192: the 16x16 level's fused q/k/v projection (23 us against 26-33 for the other tiles)
+    if (n160 && !conv && K >= 256 && (t256 == 256 || t256 == 384 || t256 == 512 || (t256 >= 192 && t256 < 256))) return 51;  // K < 256 (the im2col input conv, one K tile): nothing for loaders to do, 128x160 is 15 us against 20  // 192: the 16x16 level's fused q/k/v projection (23 us against 26-33 for the other tiles)
     if (!n160 && conv && N % 128 == 0 && N >= 256 && t256 >= 512) return 53;
   }
-  if ((tune & 1) && !conv && n160 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
+  if ((tune & 1) && !conv && n160 && K >= 256 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
   if (t128 >= 512) return n160 ? 0 : 2;
   // Round 3 (late), measured INSIDE the step (TSD_GEMM_CFG_OVERRIDE + scripts/instep_sweep.sh; the repeated-launch microbenchmark
   // keeps the operands in the L2 and ranks these the other way round): dense GEMMs with exactly one 128-row tile per CU run the
@@ -1339,6 +1340,9 @@ static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
   int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? k.sk_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV));
   // halo-x measured: -3...5 % on the 128x128-tile convs of the VAE (N = 128 / 256 / 512), nothing on the 128x160 ones (TSD_CONV_HALO=2 turns those on too)
   if (CONV && g_force_cfg < 0 && hx_eligible(k) && (id == 2 || (id == 0 && hx_mode() >= 2))) id += 30;
+  // the fused-skip variant of the 128x128 two-blocks-per-CU tile spills (48 B of scratch per lane); its 64-row sibling does not: the
+  // decoder's 256 -> 128 residual block at 512 x 512 (K = 1152 + 256) runs 1.18 ms instead of 1.35 (in-step sweep), same bits
+  if (CONV && g_force_cfg < 0 && k.Cin1 > 0 && id == 2) id = 3;
   if ((id == 30 || id == 32) && !(CONV && hx_shape_ok(k))) TSD_FAIL(TSD_E_ARG, "gemm: halo-x tile configuration %d on an ineligible problem", id);
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
