@@ -358,6 +358,8 @@ _sa_case("self_attention_d80", 64, 640, 8, False)
 _sa_case("self_attention_d160", 64, 1280, 8, False)
 _sa_case("self_attention_d40_ragged", 72, 320, 8, False)   # Tq/Tk tails inside one 64-key tile + second tile
 _sa_case("self_attention_vae_1head", 64, 128, 1, True)     # VAE style: one head, biases on (unfused path)
+_sa_case("self_attention_d80_T96", 96, 640, 8, False)      # fused q/k/v projection with a partial row tile (96 = 3 passes of 32 tokens)
+_sa_case("self_attention_d80_T96_bias", 96, 640, 8, True)  # ... and the bias over all 3C columns, V rows included
 # The fused core keeps a lazily updated softmax reference (kernels_attn.hip, TSD_ATTN_LAZY): these rows make the running maximum
 # climb by 30-45 log2 units across three to six key tiles (and start far below / above zero), so the reference-move path runs.
 _sa_case("self_attention_d40_rising_scores", 320, 320, 8, False, ramp=(0.25, 4.5), tol=5e-3, tol_max=1e-2)

@@ -165,6 +165,7 @@ def test_fused_skip_conv_equals_separate_skip_gemm(gpu_ctx, tsd_mod, name):
 
 
 @pytest.mark.parametrize("name", ["self_attention_d40", "self_attention_d80", "self_attention_d160", "self_attention_vae_1head",
+                                  "self_attention_d80_T96", "self_attention_d80_T96_bias",
                                   "unet_attn_8x80", "unet_attn_8x160", "vae_attention_512"])
 def test_fused_qkv_projection_equals_two_launches(gpu_ctx, tsd_mod, name):
     """helpers/attention.mojo:29-31 `in_proj` + chunk: q | k token-major and V^T channel-major from ONE GEMM whose tiles beyond column
