@@ -302,13 +302,15 @@ extern "C" int tsd_session_step(tsd_session* s, int i) {
     lat_in = s->lat2;
   }
   ctx->arena.top = 0;
-  TSD_TRY(g_unet_forward(s->unet, lat_in, s->ctx16, s->T, s->Tp, s->temb, Bu, L, s->eps));
+  // eps stays in the output convolution's layout ([B][L*L][4]); the DDPM update reads it as such (no conversion launch)
+  const bool eps_nhwc = s->unet->unet.final_conv.Opad == 4;  // g_unet_forward's condition for writing that layout
+  TSD_TRY(g_unet_forward(s->unet, lat_in, s->ctx16, s->T, s->Tp, s->temb, Bu, L, s->eps, eps_nhwc));
   ctx->arena.top = 0;
   float sa, sb, c_x0, c_xt, sigma;
   ddpm_coeffs(s, t, &sa, &sb, &c_x0, &c_xt, &sigma);
   const float* nz = (s->has_noise && t > 0) ? s->noise + (size_t)i * nl : nullptr;
   return launch_ddpm_step(ctx, s->latents, s->eps, s->cfg ? s->eps + nl : nullptr, s->cfg_scale, nz, (int64_t)nl, sa, sb,
-                          c_x0, c_xt, sigma);
+                          c_x0, c_xt, sigma, eps_nhwc ? L * L : 0);
 }
 
 extern "C" int tsd_session_add_noise(tsd_session* s, int i, const float* noise) {

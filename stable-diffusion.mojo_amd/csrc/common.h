@@ -224,7 +224,7 @@ int launch_transpose_f32_to_f16(tsd_ctx* ctx, const float* src, int batch, int K
                                 int Npad);
 int launch_ddpm_step(tsd_ctx* ctx, float* latents, const float* eps, const float* eps_uncond, float cfg_scale,
                      const float* noise, int64_t n, float inv_sqrt_a, float sqrt_b, float c_x0, float c_xt,
-                     float sigma);
+                     float sigma, int eps_hw = 0);  // eps_hw > 0: eps in the output convolution's layout [B][eps_hw][4]
 int launch_add_noise(tsd_ctx* ctx, float* latents, const float* noise, int64_t n, float sa, float sb);
 int launch_encoder_sample(tsd_ctx* ctx, const float* moments_nhwc, int B, int HW, int ld, const float* noise_chw,
                           float* latents_chw);

@@ -416,11 +416,11 @@ int g_vae_attn(tsd_ctx* ctx, const Act& x, const VaeAttnW& w, Act& out) {
 
 // ---- `Diffusion.forward` diffusion.mojo:309-318 -------------------------------------------------------
 static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp,
-                               const float* temb, int B, int L, float* eps_out_chw);
+                               const float* temb, int B, int L, float* eps_out_chw, bool eps_nhwc);
 
 int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
-                   int L, float* eps_out_chw) {
-  if (is_full_unet_kind(m->kind)) return g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw);
+                   int L, float* eps_out_chw, bool eps_nhwc) {
+  if (is_full_unet_kind(m->kind)) return g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw, eps_nhwc);
   tsd_ctx* ctx = m->ctx;
   const UNetW& u = m->unet;
   if (L % 8) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 8", L);
@@ -523,9 +523,11 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   Act hf = act_alloc(ctx, B, L, L, 320); CHECK_ALLOC(hf.p);
   TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(a[23]), 320), B, L * L, 320, 320, 1e-5f, 1.f, 1, hf.p, hf.ld,
                            a[23].gn_groups == 320 ? a[23].gn_part : nullptr, a[23].gn_nslab));
-  float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
-  TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
-  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));
+  if (eps_nhwc && u.final_conv.Opad == 4)  // the caller reads [B][L*L][4] directly
+    return g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_out_chw, 4);
+  float* eps_tmp = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_tmp);
+  TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_tmp, 4));
+  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_tmp, B, 4, L, L, 4, eps_out_chw));
   return TSD_OK;
 }
 
@@ -533,7 +535,7 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
 // Encoders push their output; every decoder residual block reads concat(x, popped skip) through the two-source views;
 // Upsample + conv3x3 is one implicit-GEMM launch that reads its input through the nearest-2x addressing.
 static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp,
-                               const float* temb, int B, int L, float* eps_out_chw) {
+                               const float* temb, int B, int L, float* eps_out_chw, bool eps_nhwc) {
   tsd_ctx* ctx = m->ctx;
   const UNetW& u = m->unet;
   if (L % 16) TSD_FAIL(TSD_E_SHAPE, "full-size UNet: latent side %d must be a multiple of 16", L);
@@ -624,9 +626,11 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
   TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(cur), 320), B, L * L, 320, u.final_groups, 1e-5f, 1.f, 1, hf.p, hf.ld,
                            cur.gn_groups == u.final_groups ? cur.gn_part : nullptr, cur.gn_nslab,
                            u.final_gn.w ? &u.final_gn : nullptr));
-  float* eps_nhwc = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_nhwc);
-  TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_nhwc, 4));
-  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_nhwc, B, 4, L, L, 4, eps_out_chw));
+  if (eps_nhwc && u.final_conv.Opad == 4)  // the caller reads [B][L*L][4] directly
+    return g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_out_chw, 4);
+  float* eps_tmp = arena_alloc<float>(ctx, (int64_t)B * L * L * 4); CHECK_ALLOC(eps_tmp);
+  TSD_TRY(g_conv3x3(ctx, hf, u.final_conv, 1, 1, 1, 0, nullptr, 0, nullptr, 0, true, eps_tmp, 4));
+  TSD_TRY(launch_nhwc_f32_to_chw_f32(ctx, eps_tmp, B, 4, L, L, 4, eps_out_chw));
   return TSD_OK;
 }
 

@@ -54,8 +54,10 @@ int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& i
 
 // module forwards on device buffers
 // latents: fp32 CHW [B,4,L,L]; context16: fp16 [B][Tp][768]; temb: fp32 [B][320]; eps_out: fp32 CHW [B,4,L,L]
+// eps_nhwc: eps_out receives the output convolution's own layout, fp32 [B][L*L][4], instead of CHW (the denoise session's DDPM update
+// reads it directly: one conversion launch per step less)
 int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
-                   int L, float* eps_out_chw);
+                   int L, float* eps_out_chw, bool eps_nhwc = false);
 int g_decoder_forward(tsd_model* m, const float* latents_chw, int B, int L, float* images_chw);
 int g_encoder_forward(tsd_model* m, const float* images_chw, const float* noise_chw, int B, int S, float* latents_chw);
 

@@ -355,6 +355,17 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem_sl[];
   float* xs = (float*)smem_sl;  // [B][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the lane's weight chunks of the first (for K <= 2048: the only) pass are requested BEFORE the activations are staged: the
+  // two round trips (weights cold from HBM, activations from the previous launch) overlap instead of following each other
+  const int col = lane >> 4, sub = lane & 15;  // column within the wave's 4, lane within the column's 16
+  const int n = blockIdx.x * 16 + wave * 4 + col;
+  const half_t* wr = w + (int64_t)min(n, N - 1) * ldw;
+  h8 wv0[SL_KIT];
+#pragma unroll
+  for (int it = 0; it < SL_KIT; it++) {
+    const int k0 = it * 128 + sub * 8;
+    wv0[it] = k0 < K ? *(const h8*)(wr + k0) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
   // activations -> LDS (with the fused SiLU): batches of 8 independent 16-B loads per thread (K % 4 == 0)
   const int nvec = (B * K) >> 2;
   for (int i0 = tid; i0 < nvec; i0 += 256 * 8) {
@@ -380,9 +391,6 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
     }
   }
   __syncthreads();
-  const int col = lane >> 4, sub = lane & 15;  // column within the wave's 4, lane within the column's 16
-  const int n = blockIdx.x * 16 + wave * 4 + col;
-  const half_t* wr = w + (int64_t)min(n, N - 1) * ldw;
   float acc[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) acc[b] = 0.f;
@@ -391,7 +399,8 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 #pragma unroll
     for (int it = 0; it < SL_KIT; it++) {
       const int k0 = kbase + it * 128 + sub * 8;
-      wv[it] = k0 < K ? *(const h8*)(wr + k0) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (kbase == 0) wv[it] = wv0[it];
+      else wv[it] = k0 < K ? *(const h8*)(wr + k0) : h8{0, 0, 0, 0, 0, 0, 0, 0};
     }
 #pragma unroll
     for (int it = 0; it < SL_KIT; it++) {
@@ -559,13 +568,19 @@ int launch_pack_bias(tsd_ctx* ctx, const float* src, int N, float* dst, int Npad
 }
 
 // ---- DDPM update + CFG combine (sampler.mojo:75-109, pipeline.mojo:117-119; App.D K9) ------------
+// eps_hw > 0: eps / eps_u are the UNet output convolution's own layout [B][eps_hw][4] (x and noise stay CHW [B][4][eps_hw])
 __global__ void k_ddpm_step(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ eps_u,
                             float cfg_scale, const float* __restrict__ noise, int64_t n, float sa, float sb,
-                            float c_x0, float c_xt, float sigma) {
+                            float c_x0, float c_xt, float sigma, int eps_hw) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float e = eps[i];
+    int64_t ie = i;
+    if (eps_hw > 0) {
+      const int64_t bc = i / eps_hw, pix = i - bc * eps_hw, b = bc >> 2;
+      ie = (b * eps_hw + pix) * 4 + (bc & 3);
+    }
+    float e = eps[ie];
     if (eps_u) {
-      const float u = eps_u[i];
+      const float u = eps_u[ie];
       e = (e - u) * cfg_scale + u;
     }
     const float xv = x[i];
@@ -576,11 +591,11 @@ __global__ void k_ddpm_step(float* __restrict__ x, const float* __restrict__ eps
   }
 }
 int launch_ddpm_step(tsd_ctx* ctx, float* latents, const float* eps, const float* eps_uncond, float cfg_scale,
-                     const float* noise, int64_t n, float sa, float sb, float c_x0, float c_xt, float sigma) {
+                     const float* noise, int64_t n, float sa, float sb, float c_x0, float c_xt, float sigma, int eps_hw) {
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_ddpm_step, GRID1D(n, 256), dim3(256), 0, ctx->stream, latents, eps, eps_uncond, cfg_scale,
-                     noise, n, sa, sb, c_x0, c_xt, sigma);
+                     noise, n, sa, sb, c_x0, c_xt, sigma, eps_hw);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
