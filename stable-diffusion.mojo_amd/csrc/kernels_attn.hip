@@ -54,6 +54,8 @@ struct AttnK {
   int H, Sq, Sk, Skv;  // Skv: number of valid V^T columns (Sk rounded up to 8)
   float c;             // scale * log2(e)
   int diag;            // self-attention (Sq == Sk): the optimistic reference also covers each query's own 32-key block
+  int xcd_map;         // 1: (head, query tile) remapped so that every XCD (dispatch id % 8) owns whole heads - its L2 then pulls a head's
+                       // K / V^T once instead of every XCD pulling every head's (needs B*H % 8 == 0)
 };
 
 __device__ __forceinline__ void glds16a(const void* g, void* l) {
@@ -112,8 +114,14 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
+  int bx = blockIdx.x, bh = blockIdx.y;
+  if (p.xcd_map) {  // bijective on the grid: id -> (xcd = id % 8, j = id / 8) -> query tile j % nq of head xcd + 8 * (j / nq)
+    const int nq = gridDim.x, id = bx + nq * bh, j = id >> 3;
+    bx = j % nq;
+    bh = (id & 7) + 8 * (j / nq);
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = bx * (128 * QB) + wave * (32 * QB);
 
   const half_t* Qb = p.Q + b * p.sQ + h * D;
   const half_t* Kb = p.K + b * p.sK + h * D;
@@ -524,6 +532,12 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   k.H = a.H; k.Sq = a.Sq; k.Sk = a.Sk; k.Skv = std::min(round_up(a.Sk, 8), a.ldvt);
   k.c = a.scale * 1.4426950408889634f;
   k.diag = (g_attn_diag && a.Sq == a.Sk) ? 1 : 0;
+  // long key loops only (the K / V^T stream of a head is what the remap saves); results do not depend on the block order.
+  // Measured (profiles/r03_attn_xcd_ab.txt): FETCH_SIZE of the 4096 x 4096 d = 40 call 366 -> 144 MB, of the 1024 x 1024 d = 80 call
+  // 103 -> 33 MB (-0.9 GB of a step's 10.9 GB) and 201.1 against 201.5 steps/s - the kernel is not bound by that stream (all of it
+  // Infinity-Cache hits) and eight whole heads per XCD (5.2 MB of K / V^T) no longer fit its 4 MB L2.  OFF by default (TSD_ATTN_XCD=1).
+  static const int xcd_on = getenv("TSD_ATTN_XCD") ? atoi(getenv("TSD_ATTN_XCD")) : 0;
+  k.xcd_map = (xcd_on && (a.B * a.H) % 8 == 0 && a.Sk >= 512) ? 1 : 0;
   switch (a.d) {
     case 40:
       // 64 queries per wave when the key loop is long enough to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (half the
