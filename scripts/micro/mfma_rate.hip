@@ -5,10 +5,11 @@
 #include <cstdio>
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ unsigned long long g_ts[4];
 
-template <int SHAPE, int NACC, int ZERO>  // SHAPE 0: 16x16x32, 1: 32x32x16 ; ZERO: operands all zero
+template <int SHAPE, int NACC, int ZERO>  // SHAPE 0: 16x16x32, 1: 32x32x16, 2: 32x32x8 (legacy, 4 halves per lane), 3: 16x16x16 (legacy) ; ZERO: operands all zero
 __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned seed) {
   h8 a[4], b[2];
   unsigned s = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
@@ -21,6 +22,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned seed) {
 #pragma unroll
     for (int i = 0; i < NACC; i++) {
       if (SHAPE == 0) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 3], b[(i >> 2) & 1], acc4[i], 0, 0, 0);
+      else if (SHAPE == 2) { const h4 a4 = {a[i & 3][0], a[i & 3][1], a[i & 3][2], a[i & 3][3]}, b4 = {b[(i >> 2) & 1][0], b[(i >> 2) & 1][1], b[(i >> 2) & 1][2], b[(i >> 2) & 1][3]}; acc16[i] = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, acc16[i], 0, 0, 0); }
+      else if (SHAPE == 3) { const h4 a4 = {a[i & 3][0], a[i & 3][1], a[i & 3][2], a[i & 3][3]}, b4 = {b[(i >> 2) & 1][0], b[(i >> 2) & 1][1], b[(i >> 2) & 1][2], b[(i >> 2) & 1][3]}; acc4[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc4[i], 0, 0, 0); }
       else acc16[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i >> 2) & 1], acc16[i], 0, 0, 0);
     }
   }
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned seed) {
 template <int SHAPE, int NACC, int ZERO>
 void run(float* out, int bpc, const char* name) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  const int iters = SHAPE == 0 ? 400000 / NACC * 8 : 200000 / NACC * 8;
+  const int iters = (SHAPE == 0 || SHAPE == 3) ? 400000 / NACC * 8 : 200000 / NACC * 8;
   k<SHAPE, NACC, ZERO><<<256 * bpc, 256>>>(out, iters / 10, 1u);
   (void)hipEventRecord(e0);
   k<SHAPE, NACC, ZERO><<<256 * bpc, 256>>>(out, iters, 2u);
@@ -54,6 +57,8 @@ int main() {
     if (bpc == 2) { run<0, 8, 0>(out, 2, "16x16x32 f16, 8 accumulators"); run<1, 8, 0>(out, 2, "32x32x16 f16, 8 accumulators"); }
     if (bpc == 4) { run<0, 8, 0>(out, 4, "16x16x32 f16, 8 accumulators"); run<1, 8, 0>(out, 4, "32x32x16 f16, 8 accumulators"); }
   }
+  run<2, 8, 0>(out, 4, "32x32x8 f16 (legacy), 8 acc [flops printed as if x16]");
+  run<3, 8, 0>(out, 4, "16x16x16 f16 (legacy), 8 acc [flops as if x32]");
   run<0, 8, 1>(out, 4, "16x16x32 f16, zero operands");
   run<1, 8, 1>(out, 4, "32x32x16 f16, zero operands");
   run<0, 2, 0>(out, 4, "16x16x32 f16, 2 accumulators");
