@@ -250,6 +250,55 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const T* __restrict__ x, i
   const float inv = 1.f / s;
   for (int c = tid; c < cols; c += 256) yr[c] = (T)(__expf((float)xr[c] - m) * inv);
 }
+// fp16 rows of up to 256 * 8 * NV columns (cols % 8 == 0), in place: the row is read ONCE into registers (16-B loads), reduced,
+// and written once.  The VAE attention's 4096 x 4096 score matrices (vae.mojo:17-27 via helpers/attention.mojo:46-58) are 268 MB
+// per batch of 8: the generic kernel above walks each row three times with 2-byte accesses (0.31 ms of the decode).
+template <int NV>
+__global__ __launch_bounds__(256) void k_softmax_rows_h8(half_t* __restrict__ x, int cols, int ld) {
+  __shared__ float red[8];
+  half_t* xr = x + (int64_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  h8 v[NV];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    const int c = (tid + q * 256) * 8;
+    if (c < cols) {
+      v[q] = *(const h8*)(xr + c);
+#pragma unroll
+      for (int j = 0; j < 8; j++) m = fmaxf(m, (float)v[q][j]);
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float e[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    const int c = (tid + q * 256) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { e[q][j] = __expf((float)v[q][j] - m); s += e[q][j]; }
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  s = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    const int c = (tid + q * 256) * 8;
+    if (c < cols) {
+      h8 o;
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = (half_t)(e[q][j] * inv);
+      *(h8*)(xr + c) = o;
+    }
+  }
+}
 int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols, float* y) {
   if (!ctx->launch()) return TSD_OK;
   hipLaunchKernelGGL(k_softmax_rows<float>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, x, cols, cols, y, cols, 0, 0);
@@ -259,6 +308,12 @@ int launch_softmax_rows_f32(tsd_ctx* ctx, const float* x, int64_t rows, int cols
 int launch_softmax_rows_f16(tsd_ctx* ctx, half_t* x, int64_t rows, int cols, int ld) {
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_SOFTMAX);
+  if (cols % 8 == 0 && ld % 8 == 0 && cols <= 256 * 8 * 2) {  // register-resident rows
+    if (cols <= 256 * 8) hipLaunchKernelGGL(k_softmax_rows_h8<1>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, x, cols, ld);
+    else hipLaunchKernelGGL(k_softmax_rows_h8<2>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, x, cols, ld);
+    HIP_TRY(hipGetLastError());
+    return TSD_OK;
+  }
   hipLaunchKernelGGL(k_softmax_rows<half_t>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const half_t*)x, cols,
                      ld, x, ld, 0, 0);
   HIP_TRY(hipGetLastError());
