@@ -192,7 +192,7 @@ int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int
                                half_t* dst, int Cdst);
 // [B][C][H][W] fp32 (C <= 7) -> im2col rows [B*H*W][64] fp16 of a 3x3 / stride 1 / pad 1 convolution: column t*C + c = tap t, channel c
 // (zero outside the image and beyond 9*C); launch_pack_im2col_w builds the matching [O][64] weight matrix from packed conv weights
-int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst);
+int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst, float scale = 1.f);
 int launch_pack_im2col_w(tsd_ctx* ctx, const half_t* w, int O, int Ipad, int C, half_t* dst);
 int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst);
 int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int ld, float* dst);

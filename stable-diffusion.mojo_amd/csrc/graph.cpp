@@ -635,6 +635,12 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
 }
 
 // ---- VAE (vae.mojo:131-159, :221-250) -------------------------------------------------------------------
+// The first convolution of either VAE half reads 3 / 4 channels padded to 64: as in the UNet (g_unet_forward) the boundary gathers im2col
+// rows and the layer runs as one 64-deep K tile
+static bool vae_in_im2col(const tsd_model* m, const LayerDef* layers) {
+  static const int on = getenv("TSD_CONV_IN_IM2COL") ? atoi(getenv("TSD_CONV_IN_IM2COL")) : 1;
+  return on && m->vae.conv_in_im2col && layers[0].kind == L_CONV && layers[0].c == 3 && !m->vae.conv.empty() && m->vae.conv[0].I <= 7;
+}
 static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, bool final_f32, float* out_nhwc_f32,
                    int* out_side, int* out_ld) {
   tsd_ctx* ctx = m->ctx;
@@ -686,7 +692,10 @@ static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, 
         return TSD_OK;
       }
       Act y = act_alloc_gn(ctx, B, side, side, w.Opad, next_groups(i)); CHECK_ALLOC(y.p);
-      if (l.c == 3) TSD_TRY(g_conv3x3(ctx, cur, w, stride, pad, pad_br, pending_up, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
+      if (i == 0 && vae_in_im2col(m, layers))  // cur holds im2col rows [B*H*W][64]
+        TSD_TRY(g_linear(ctx, cat1(cur), (int64_t)B * side * side, v.conv_in_im2col, 64, w.Opad, 64, w.b, nullptr, 0, 0, y.p, y.ld, &y,
+                         side * side));
+      else if (l.c == 3) TSD_TRY(g_conv3x3(ctx, cur, w, stride, pad, pad_br, pending_up, nullptr, 0, nullptr, 0, false, y.p, y.ld, &y));
       else TSD_TRY(g_linear(ctx, cat1(cur), (int64_t)B * side * side, w.w, w.Ipad, w.Opad, w.Ipad, w.b, nullptr, 0, 0, y.p, y.ld, &y,
                             side * side));
       pending_up = 0;
@@ -711,7 +720,8 @@ int g_decoder_forward(tsd_model* m, const float* latents_chw, int B, int L, floa
   tsd_ctx* ctx = m->ctx;
   if (L % 8) TSD_FAIL(TSD_E_SHAPE, "decoder: latent side %d must be a multiple of 8", L);
   Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
-  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f / 0.18215f, x0.p, 64));  // vae.mojo:222
+  if (vae_in_im2col(m, DECODER_LAYERS)) TSD_TRY(launch_chw_f32_to_im2col3x3_f16(ctx, latents_chw, B, 4, L, L, x0.p, 1.f / 0.18215f));
+  else TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f / 0.18215f, x0.p, 64));  // vae.mojo:222
   const int S = 8 * L;
   float* img = arena_alloc<float>(ctx, (int64_t)B * S * S * 4); CHECK_ALLOC(img);
   int side = 0, ld = 0;
@@ -725,7 +735,8 @@ int g_encoder_forward(tsd_model* m, const float* images_chw, const float* noise_
   tsd_ctx* ctx = m->ctx;
   if (S % 64) TSD_FAIL(TSD_E_SHAPE, "encoder: image side %d must be a multiple of 64", S);
   Act x0 = act_alloc(ctx, B, S, S, 64); CHECK_ALLOC(x0.p);
-  TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, images_chw, B, 3, S, S, 3, 1.f, x0.p, 64));
+  if (vae_in_im2col(m, ENCODER_LAYERS)) TSD_TRY(launch_chw_f32_to_im2col3x3_f16(ctx, images_chw, B, 3, S, S, x0.p));
+  else TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, images_chw, B, 3, S, S, 3, 1.f, x0.p, 64));
   const int L = S / 8;
   float* mom = arena_alloc<float>(ctx, (int64_t)B * L * L * 8); CHECK_ALLOC(mom);
   int side = 0, ld = 0;

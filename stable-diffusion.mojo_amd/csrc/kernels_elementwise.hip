@@ -48,7 +48,7 @@ int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int
 // im2col rows of a 3x3 / stride 1 / pad 1 convolution over a C-channel (C <= 7) fp32 CHW image: one thread per 16-B chunk of a
 // 64-wide row; column t*C + c = tap t = (kh, kw), channel c.  The 4-channel latent padded to 64 channels cost the input
 // convolution nine K tiles of which 1/16 carried data (diffusion.mojo:236 `Conv2D(4, 320, 3)`).
-__global__ void k_chw_to_im2col3x3(const float* __restrict__ src, int C, int H, int W, half_t* __restrict__ dst, int64_t total_chunks) {
+__global__ void k_chw_to_im2col3x3(const float* __restrict__ src, int C, int H, int W, half_t* __restrict__ dst, int64_t total_chunks, float scale) {
   const int HW = H * W;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
     const int cc = (int)(i & 7);
@@ -61,17 +61,17 @@ __global__ void k_chw_to_im2col3x3(const float* __restrict__ src, int C, int H, 
       const int col = cc * 8 + j, t = col / C, c = col - t * C;
       const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
       const bool ok = t < 9 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      v[j] = ok ? (half_t)src[(b * C + c) * HW + iy * W + ix] : (half_t)0.f;
+      v[j] = ok ? (half_t)(src[(b * C + c) * HW + iy * W + ix] * scale) : (half_t)0.f;
     }
     *(h8*)(dst + pixg * 64 + cc * 8) = v;
   }
 }
-int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst) {
+int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst, float scale) {
   if (C <= 0 || 9 * C > 64) TSD_FAIL(TSD_E_SHAPE, "im2col: %d channels do not fit a 64-wide row", C);
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = (int64_t)B * H * W * 8;
   ProfScope prof(ctx, KC_ELEMENTWISE);
-  hipLaunchKernelGGL(k_chw_to_im2col3x3, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H, W, dst, total);
+  hipLaunchKernelGGL(k_chw_to_im2col3x3, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H, W, dst, total, scale);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

@@ -23,6 +23,7 @@ static void model_invalidate_derived(tsd_model* m) {
   m->ready = false;
   for (auto& a : m->unet.attn) { a.tail_stream = nullptr; a.head_stream = nullptr; }
   m->unet.conv_in_im2col = nullptr;
+  m->vae.conv_in_im2col = nullptr;
 }
 
 static size_t packed_bytes(const ParamSpec& p) {
@@ -158,8 +159,28 @@ extern "C" int tsd_model_mark_loaded(tsd_model* m) {
 
 // derived device buffers (not part of the broadcast blob: every rank rebuilds them from the packed weights)
 static int model_build_derived(tsd_model* m) {
-  if (!is_diffusion_kind(m->kind)) return TSD_OK;
   tsd_ctx* ctx = m->ctx;
+  if (is_decoder_kind(m->kind) || is_encoder_kind(m->kind)) {  // first convolution of the VAE halves: im2col weights
+    if (m->vae.conv.empty()) return TSD_OK;
+    const ConvW& c0 = m->vae.conv[0];
+    if (!(c0.w && c0.k == 3 && c0.I > 0 && 9 * c0.I <= 64 && c0.Ipad == 64)) return TSD_OK;
+    const size_t need = (size_t)c0.Opad * 64 * sizeof(half_t);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (m->derived_bytes < need) {
+      if (m->derived) HIP_TRY(hipFree(m->derived));
+      m->derived = nullptr; m->derived_bytes = 0;
+      hipError_t e = hipMalloc((void**)&m->derived, need);
+      if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "derived weights: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+      m->derived_bytes = need;
+    }
+    const bool wp = ctx->arena.planning;
+    ctx->arena.planning = false;
+    const int r = launch_pack_im2col_w(ctx, c0.w, c0.Opad, c0.Ipad, c0.I, (half_t*)m->derived);
+    ctx->arena.planning = wp;
+    if (r == TSD_OK) m->vae.conv_in_im2col = (const half_t*)m->derived;
+    return r;
+  }
+  if (!is_diffusion_kind(m->kind)) return TSD_OK;
   std::vector<AttnW*> el;
   for (auto& a : m->unet.attn) if (a.C && (attn_tail_weights_ok(a) || attn_head_weights_ok(a))) el.push_back(&a);
   // input convolution (4 latent channels): [Opad][64] im2col weights

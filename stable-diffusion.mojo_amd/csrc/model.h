@@ -96,6 +96,7 @@ struct UNetW {
 };
 struct VaeW {
   std::vector<ConvW> conv;      // indexed by layer (1-based position - 1)
+  const half_t* conv_in_im2col = nullptr;  // derived: the first convolution (3 or 4 input channels) as [Opad][64] im2col weights
   std::vector<ResW> res;
   std::vector<VaeAttnW> attn;
   std::vector<NormAffine> gn;   // stand-alone GroupNorm layers (torch-norm extension)
