@@ -184,6 +184,8 @@ struct GemmArgs {
   int rows_per_sample_hint = 0;
 };
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a);
+// slices of the long-K split launches (K >= 8192, 16x16 level) for the graph being enqueued on this thread; returns the previous value
+int gemm_set_splitk_big(int ways);
 int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups);  // 0: not available
 
 // ---- other kernel launchers -----------------------------------------------------------

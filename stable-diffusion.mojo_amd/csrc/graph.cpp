@@ -420,7 +420,12 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
 
 int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
                    int L, float* eps_out_chw, bool eps_nhwc) {
-  if (is_full_unet_kind(m->kind)) return g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw, eps_nhwc);
+  if (is_full_unet_kind(m->kind)) {
+    const int prev = gemm_set_splitk_big(4);  // measured for this graph at its batch of 4 (BASELINE configs[4]): +4.3 %
+    const int r = g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw, eps_nhwc);
+    gemm_set_splitk_big(prev);
+    return r;
+  }
   tsd_ctx* ctx = m->ctx;
   const UNetW& u = m->unet;
   if (L % 8) TSD_FAIL(TSD_E_SHAPE, "UNet: latent side %d must be a multiple of 8", L);

@@ -1212,6 +1212,8 @@ static bool xcd_round_robin() {
 }
 extern "C" int tsd_debug_xcd_round_robin(void) { return xcd_round_robin() ? 1 : 0; }
 
+static thread_local int g_sk_big_graph = 0;  // slices for K >= 8192 at the 16x16 level asked for by the running graph (0: default)
+int gemm_set_splitk_big(int ways) { const int prev = g_sk_big_graph; g_sk_big_graph = ways; return prev; }
 // Split-K plan: number of K slices (1 = none) and the tile configuration the split launch runs with.
 static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   static const int on = getenv("TSD_GEMM_SPLITK") ? atoi(getenv("TSD_GEMM_SPLITK")) : 1;
@@ -1240,7 +1242,10 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
     static const int deep = getenv("TSD_GEMM_SPLITK_RING4") ? atoi(getenv("TSD_GEMM_SPLITK_RING4")) : 0;
     if (cfg) *cfg = deep ? (n160 ? 6 : 9) : (n160 ? 7 : 10);
   } else {
-    static const int big_ways = getenv("TSD_GEMM_SPLITK_BIG") ? atoi(getenv("TSD_GEMM_SPLITK_BIG")) : 2;
+    static const int big_env = getenv("TSD_GEMM_SPLITK_BIG") ? atoi(getenv("TSD_GEMM_SPLITK_BIG")) : 0;
+    // 2 slices for the 23-layer UNet at batch 8; the full-size UNet's graph asks for 4 (gemm_set_splitk_big: +4.3 % at its batch of 4,
+    // -0.8 % on the headline).  A per-GRAPH choice, so every batch size of a model sums in the same tree.
+    const int big_ways = big_env ? big_env : (g_sk_big_graph ? g_sk_big_graph : 2);
     ways = K >= 8192 ? big_ways : (K >= min_k ? 2 : 1);
     if (wide && ways == 2 && ceil_div(N, BN) <= 4) ways = 4;
     if (mid) ways = 2;
@@ -1298,7 +1303,7 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   if ((tune & 4) && M % 256 == 0) {
     if (n160 && conv && t256 >= 256 && t256 % 256 == 0) return 51;
     if (n160 && !conv && K >= 256 && (t256 == 256 || t256 == 384 || t256 == 512 || (t256 >= 192 && t256 < 256))) return 51;  // K < 256 (the im2col input conv, one K tile): nothing for loaders to do, 128x160 is 15 us against 20  // 192: the 16x16 level's fused q/k/v projection (23 us against 26-33 for the other tiles)
-    if (!n160 && conv && N % 128 == 0 && N >= 256 && t256 >= 512) return 53;
+    if (!n160 && conv && N % 128 == 0 && N >= 256 && t256 >= 512 && K >= 2304) return 53;  // K = 1152 (128 -> 256 at 256 x 256): 128x128 tiles, 0.42 vs 0.45 ms in-step
   }
   if ((tune & 1) && !conv && n160 && K >= 256 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
   if (t128 >= 512) return n160 ? 0 : 2;
