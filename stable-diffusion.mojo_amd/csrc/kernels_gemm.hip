@@ -1315,7 +1315,10 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   if ((tune & 8) && !conv && n160 && N >= 8192 && t128 >= 384) return 0;  // few rows, very wide (context K | V^T: 34 -> 29 us)
   if (t128 >= 192) return (K >= 2560 || !(tune & 2)) ? (n160 ? 5 : 8) : (n160 ? 1 : 3);
   if (K >= 5760) return n160 ? 6 : 9;
-  if ((tune & 8) && !conv && n160 && (long long)ceil_div(M, 64) * ceil_div(N, BN) * batch == 256 && M % 64 == 0) return 47;
+  {  // 256 tiles: measured on 2048x1280x1280; 128 tiles: the full-size UNet's 1024x1280x1280 at batch 4 (0.483 -> 0.463 ms for its 25 launches)
+    const long long t64 = (long long)ceil_div(M, 64) * ceil_div(N, BN) * batch;
+    if ((tune & 8) && !conv && n160 && (t64 == 256 || t64 == 128) && M % 64 == 0 && N >= 1280) return 47;
+  }
   return n160 ? 7 : 10;
 }
 
