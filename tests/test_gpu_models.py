@@ -42,6 +42,21 @@ def test_diffusion_forward_matches_oracle(L, diffusion, unet_params):
     assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, f"Diffusion.forward L={L}")
 
 
+def test_diffusion_forward_matches_oracle_odd_sizes(diffusion, unet_params):
+    """Batch 3 at a 24 x 24 latent: 576 / 144 / 36 tokens per level - the first level takes the fused q/k/v projection, the
+    composite GroupNorm statistics and the im2col input convolution, the other two fall back (token counts that are no multiple of
+    32: two-launch projection, statistics pass) - and M is no multiple of any tile height."""
+    B, L = 3, 24
+    lat, ctx = _inputs(B, L, tag=530)
+    temb = np.stack([ops.time_embedding(t) for t in (980.0, 430.0, 20.0)])
+    out = diffusion.forward(lat, ctx, temb)
+    ref = np.stack([models.diffusion(unet_params, lat[b], ctx[b], temb[b]) for b in range(B)])
+    assert_close(out, ref, TOL_MODEL, TOL_MODEL_MAX, "Diffusion.forward B=3 L=24")
+    for b in range(B):  # and batch invariance through the mixed paths
+        single = diffusion.forward(lat[b], ctx[b], temb[b])
+        assert np.array_equal(np.asarray(single).reshape(out[b].shape), out[b]), b
+
+
 def test_device_rng_equals_host_rng(gpu_ctx, tsd_mod, diffusion, unet_params):
     """init_random on the device == uploading the numpy-generated weights: outputs must be bit-identical."""
     full = spec.init_params("diffusion", SEED)  # includes the unused tensors
