@@ -134,6 +134,9 @@ struct ConvW {  // fp16 [Opad][k*k][Ipad] (K-major for the implicit GEMM), fp32 
   const half_t* w = nullptr;
   const float* b = nullptr;
   int I = 0, O = 0, k = 0, Ipad = 0, Opad = 0;
+  // derived (model_check_ready, weight-heavy 3x3 convs only): the same weights K-tile-major, [k*k*Ipad / 64][Opad][64] - the 160 x 64
+  // tile a workgroup stages per K step is 20 KB of consecutive bytes instead of 160 rows a whole weight row (up to 46 KB) apart
+  const half_t* w_tm = nullptr;
 };
 struct LinW {  // fp16 [N][Kpad], fp32 bias [N] (nullptr when the reference passes use_bias=False)
   const half_t* w = nullptr;
@@ -166,6 +169,7 @@ struct GemmArgs {
   const half_t* A2 = nullptr; int lda2 = 0; int Cin1 = 0, Cin2 = 0;
   const half_t* Wt1 = nullptr; int ldw1 = 0;
   const half_t* Wt = nullptr; int ldw = 0;  // "W" operand [N][K]
+  int w_kts = 0;  // bytes from one 64-deep K tile of W to the next; 0 = 128 (row-major [N][K]).  K-tile-major [K/64][N][64]: ldw = 64, w_kts = N * 128
   int M = 0, N = 0, K = 0;
   int batch = 1; int64_t sA = 0, sW = 0, sC = 0, sR = 0;  // element strides per batch
   int epi = 0;
@@ -196,6 +200,7 @@ int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int
 // (zero outside the image and beyond 9*C); launch_pack_im2col_w builds the matching [O][64] weight matrix from packed conv weights
 int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst, float scale = 1.f);
 int launch_pack_im2col_w(tsd_ctx* ctx, const half_t* w, int O, int Ipad, int C, half_t* dst);
+int launch_pack_tile_major(tsd_ctx* ctx, const half_t* w, int N, int K, half_t* dst);  // [N][K] -> [K/64][N][64]
 int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst);
 int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int ld, float* dst);
 int launch_f32_to_f16_rows(tsd_ctx* ctx, const float* src, int64_t rows, int cols, half_t* dst, int ld_dst,

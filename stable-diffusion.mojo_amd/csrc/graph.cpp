@@ -49,6 +49,7 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
   g.A0 = x.p; g.lda0 = x.ld; g.conv = 1; g.Hs = x.H; g.Ws = x.W; g.Ho = Ho; g.Wo = Wo; g.Cin = w.Ipad;
   g.stride = stride; g.pad = pad; g.ups = ups;
   g.Wt = w.w; g.ldw = 9 * w.Ipad;
+  if (w.w_tm) { g.Wt = w.w_tm; g.ldw = 64; g.w_kts = w.Opad * 128; }  // K-tile-major copy (weight-heavy layers)
   g.M = x.B * Ho * Wo; g.N = w.Opad; g.K = 9 * w.Ipad;
   g.epi = EPI_BIAS_N; g.bias = w.b;
   if (rowvec) { g.epi |= EPI_ROWVEC; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = Ho * Wo; }

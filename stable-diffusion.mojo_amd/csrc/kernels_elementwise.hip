@@ -90,6 +90,24 @@ int launch_pack_im2col_w(tsd_ctx* ctx, const half_t* w, int O, int Ipad, int C, 
   return TSD_OK;
 }
 
+// [N][K] fp16 -> K-tile-major [K/64][N][64] (16-B chunks)
+__global__ void k_pack_tile_major(const half_t* __restrict__ w, int N, int K, half_t* __restrict__ dst, int64_t total_chunks) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 7);
+    const int64_t r = i >> 3;       // kt * N + n
+    const int64_t kt = r / N, n = r - kt * N;
+    *(h8*)(dst + i * 8) = *(const h8*)(w + n * K + kt * 64 + c * 8);
+  }
+}
+int launch_pack_tile_major(tsd_ctx* ctx, const half_t* w, int N, int K, half_t* dst) {
+  if (K % 64) TSD_FAIL(TSD_E_SHAPE, "tile-major pack: K=%d", K);
+  if (!ctx->launch()) return TSD_OK;
+  const int64_t total = (int64_t)N * K / 8;
+  hipLaunchKernelGGL(k_pack_tile_major, GRID1D(total, 256), dim3(256), 0, ctx->stream, w, N, K, dst, total);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
 template <class T>
 __global__ void k_nhwc_to_chw(const T* __restrict__ src, int C, int HW, int ld, float* __restrict__ dst,
                               int64_t total) {

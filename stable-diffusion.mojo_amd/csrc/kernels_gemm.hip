@@ -69,6 +69,7 @@ struct GemmK {
   // weights Wt1[n][Cin1 + Cin2]
   const half_t* A2; const half_t* Wt1; int lda2, Cin1, Cin2, ldw1;
   int epi, tiles_n, xcd_n;
+  unsigned w_kts;  // bytes from one K tile of W to the next (128: row-major)
   float out_scale;
   float* gn_part; int gn_cpg, gn_G, gn_hw, gn_nslab;  // EPI_GNSTATS
   half_t* vt; long long vt_sB; int vt_n0, vt_ld, vt_S;  // transposed tail: columns >= vt_n0 go to vt[b][n - vt_n0][s] (GemmArgs::Vt)
@@ -316,10 +317,10 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
     }
     if constexpr (SK) {
       t.rw = __builtin_amdgcn_make_buffer_rsrc((half_t*)((uintptr_t)Wt + (uintptr_t)(dW1 & (skip ? -1LL : 0LL))), 0, nrec, 0x00020000);
-      t.w_soff = skip ? ((st_tap == 9 ? 0u : k_cin1) + (unsigned)st_cc * 64) * 2 : (unsigned)k0 * 2;
+      t.w_soff = skip ? ((st_tap == 9 ? 0u : k_cin1) + (unsigned)st_cc * 64) * 2 : (unsigned)(kt0 + kt) * p.w_kts;
     } else {
       t.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Wt), 0, nrec, 0x00020000);
-      t.w_soff = k0 * 2;
+      t.w_soff = (unsigned)(kt0 + kt) * p.w_kts;
     }
     t.a_on = true; t.abuf = 0;
     if constexpr (HX) {
@@ -1526,7 +1527,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
     const long long lim = 0x7ffffff0LL - 65536;
     const long long a_bytes = a.conv ? 2LL * (a.M / (a.Ho * a.Wo)) * a.Hs * a.Ws * a.lda0
                                      : 2LL * ((long long)(a.M - 1) * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) + a.K);
-    const long long w_bytes = 2LL * ((long long)(a.N - 1) * a.ldw + a.K);
+    const long long w_bytes = a.w_kts ? (long long)(a.K / 64) * a.w_kts : 2LL * ((long long)(a.N - 1) * a.ldw + a.K);
     const long long s_bytes = a.conv && a.Cin1 ? 2LL * (a.M / (a.Ho * a.Wo)) * a.Hs * a.Ws * (a.lda1 > a.lda2 ? a.lda1 : a.lda2) : 0;
     if (a_bytes > lim || w_bytes > lim || s_bytes > lim)
       TSD_FAIL(TSD_E_SHAPE, "gemm: operand slice of %lld / %lld bytes exceeds the 2 GiB addressing window", a_bytes, w_bytes);
@@ -1564,6 +1565,8 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.Hs = a.Hs; k.Ws = a.Ws; k.Ho = a.Ho; k.Wo = a.Wo; k.Cin = a.Cin; k.stride = a.stride; k.pad = a.pad; k.ups = a.ups;
   k.A2 = a.A2; k.Wt1 = a.Wt1; k.lda2 = a.lda2; k.Cin1 = a.conv ? a.Cin1 : 0; k.Cin2 = a.conv ? a.Cin2 : 0; k.ldw1 = a.ldw1;
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
+  k.w_kts = a.w_kts ? (unsigned)a.w_kts : 128u;
+  if (a.w_kts && (a.ldw != 64 || a.w_kts < a.N * 128 || hx_mode() > 0)) TSD_FAIL(TSD_E_ARG, "gemm: K-tile-major W needs ldw = 64 and a tile stride >= N * 128");
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;
   k.vt = a.Vt; k.vt_sB = a.vt_sB; k.vt_n0 = a.vt_n0; k.vt_ld = a.vt_ld; k.vt_S = a.vt_S;

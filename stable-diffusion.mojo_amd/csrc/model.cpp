@@ -24,6 +24,7 @@ static void model_invalidate_derived(tsd_model* m) {
   for (auto& a : m->unet.attn) { a.tail_stream = nullptr; a.head_stream = nullptr; }
   m->unet.conv_in_im2col = nullptr;
   m->vae.conv_in_im2col = nullptr;
+  for (auto& r : m->unet.res) { r.conv1.w_tm = nullptr; r.conv2.w_tm = nullptr; }
 }
 
 static size_t packed_bytes(const ParamSpec& p) {
@@ -187,9 +188,17 @@ static int model_build_derived(tsd_model* m) {
   const ConvW& cin = is_full_unet_kind(m->kind) ? (m->unet.conv.empty() ? m->unet.conv1 : m->unet.conv[0]) : m->unet.conv1;
   const bool cin_ok = cin.w && cin.k == 3 && cin.I > 0 && 9 * cin.I <= 64 && cin.Ipad == 64;
   const size_t cin_b = cin_ok ? ((size_t)cin.Opad * 64 * sizeof(half_t) + 255) & ~size_t(255) : 0;
-  if (el.empty() && !cin_ok) return TSD_OK;
+  // weight-heavy 3x3 convs (>= TSD_CONV_W_TM MiB of weights; 0 = off): K-tile-major copies
+  static const int tm_mib = getenv("TSD_CONV_W_TM") ? atoi(getenv("TSD_CONV_W_TM")) : 2;  // measured: +0.3 % headline, +0.6 % full-size UNet (profiles/r03_conv_w_tile_major_ab.txt)
+  std::vector<ConvW*> tm;
+  size_t tm_b = 0;
+  if (tm_mib > 0)
+    for (auto& r : m->unet.res)
+      for (ConvW* c : {&r.conv1, &r.conv2})
+        if (c->w && c->k == 3 && (size_t)c->Opad * 9 * c->Ipad * 2 >= (size_t)tm_mib << 20) { tm.push_back(c); tm_b += (((size_t)c->Opad * 9 * c->Ipad * 2) + 255) & ~size_t(255); }
+  if (el.empty() && !cin_ok && tm.empty()) return TSD_OK;
   const size_t tail_b = (attn_tail_stream_bytes() + 255) & ~size_t(255), head_b = (attn_head_stream_bytes() + 255) & ~size_t(255);
-  const size_t each = tail_b + head_b, need = each * el.size() + cin_b;
+  const size_t each = tail_b + head_b, need = each * el.size() + cin_b + tm_b;
   HIP_TRY(hipSetDevice(ctx->device));
   if (m->derived_bytes < need) {
     if (m->derived) HIP_TRY(hipFree(m->derived));
@@ -219,6 +228,16 @@ static int model_build_derived(tsd_model* m) {
     half_t* dst = (half_t*)(m->derived + each * el.size());
     r = launch_pack_im2col_w(ctx, cin.w, cin.Opad, cin.Ipad, cin.I, dst);
     if (r == TSD_OK) m->unet.conv_in_im2col = dst;
+  }
+  {
+    size_t off = each * el.size() + cin_b;
+    for (size_t i = 0; i < tm.size() && r == TSD_OK; i++) {
+      ConvW* c = tm[i];
+      half_t* dst = (half_t*)(m->derived + off);
+      r = launch_pack_tile_major(ctx, c->w, c->Opad, 9 * c->Ipad, dst);
+      if (r == TSD_OK) c->w_tm = dst;
+      off += (((size_t)c->Opad * 9 * c->Ipad * 2) + 255) & ~size_t(255);
+    }
   }
   ctx->arena.planning = was_planning;
   return r;
