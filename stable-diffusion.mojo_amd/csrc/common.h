@@ -142,6 +142,7 @@ struct LinW {  // fp16 [N][Kpad], fp32 bias [N] (nullptr when the reference pass
   const half_t* w = nullptr;
   const float* b = nullptr;
   int N = 0, K = 0, Kpad = 0;
+  const half_t* w_tm = nullptr;  // derived K-tile-major copy [Kpad / 64][N][64] (see ConvW::w_tm)
 };
 
 // ---- GEMM / implicit-GEMM conv launcher (kernels_gemm.hip) ------------------------------

@@ -73,11 +73,12 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
 }
 
 int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
-             const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat, int rows_per_sample) {
+             const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat, int rows_per_sample, const half_t* w_tm) {
   GemmArgs g;
   g.A0 = a.p0; g.lda0 = a.ld0;
   if (a.p1 && K > a.C0) { g.A1 = a.p1; g.lda1 = a.ld1; g.K0 = a.C0; }
   g.Wt = w; g.ldw = ldw; g.M = (int)M; g.N = N; g.K = K;
+  if (w_tm) { g.Wt = w_tm; g.ldw = 64; g.w_kts = N * 128; }
   g.epi = epi_extra;
   if (bias) { g.epi |= EPI_BIAS_N; g.bias = bias; }
   if (res) { g.epi |= EPI_RESIDUAL; g.R = res; g.ldr = ldr; }
@@ -217,7 +218,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     TSD_TRY(launch_groupnorm(ctx, norm_src(cat1(x), C), B, S, C, 32, 1e-6f, 1.f, 0, h0, C, x_stats ? x.gn_part : nullptr,
                              x.gn_nslab, w.gn.w ? &w.gn : nullptr));  // :89,:116
     a.p0 = h0; a.ld0 = C; a.C0 = C;
-    TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C, nullptr, S));  // :117
+    TSD_TRY(g_linear(ctx, a, M, w.conv_in.w, w.conv_in.Ipad, C, C, w.conv_in.b, nullptr, 0, 0, tok, C, nullptr, S, w.conv_in.w_tm));  // :117
     if (Sp != S) TSD_TRY(zero_async(ctx, vt, (size_t)B * C * Sp * sizeof(half_t)));  // pad keys must be finite (P = 0 there)
     // ---- self attention (:122-126) ----
     TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C, w.ln[0].w ? &w.ln[0] : nullptr));
@@ -225,6 +226,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     if (qkv_fused_ok(S, Sp, C)) {  // q | k token-major and V^T channel-major from ONE GEMM over in_proj's 3C rows (transposed tail)
       GemmArgs g;
       g.A0 = ln; g.lda0 = C; g.Wt = w.sa_in.w; g.ldw = w.sa_in.Kpad; g.M = (int)M; g.N = 3 * C; g.K = C;
+      if (w.sa_in.w_tm) { g.Wt = w.sa_in.w_tm; g.ldw = 64; g.w_kts = 3 * C * 128; }
       g.C = qk; g.ldc = 2 * C; g.rows_per_sample_hint = S;
       g.Vt = vt; g.vt_n0 = 2 * C; g.vt_ld = Sp; g.vt_S = S; g.vt_sB = (int64_t)C * Sp;
       TSD_TRY(launch_gemm(ctx, g));
@@ -297,12 +299,12 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   }
   half_t* tok2 = arena_alloc<half_t>(ctx, M * C); CHECK_ALLOC(tok2);
   a.p0 = ao;
-  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C, nullptr, S));
+  TSD_TRY(g_linear(ctx, a, M, w.sa_out.w, w.sa_out.Kpad, C, C, w.sa_out.b, tok, C, 0, tok2, C, nullptr, S, w.sa_out.w_tm));
   // ---- cross attention (:129-133) ----
   TSD_TRY(launch_layernorm(ctx, tok2, M, C, C, 1e-5f, ln, C, w.ln[1].w ? &w.ln[1] : nullptr));
   half_t* q = qk;  // reuse
   a.p0 = ln;
-  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C, nullptr, S));
+  TSD_TRY(g_linear(ctx, a, M, w.ca_q.w, w.ca_q.Kpad, C, C, nullptr, nullptr, 0, 0, q, C, nullptr, S, w.ca_q.w_tm));
   fa.Q = q; fa.ldq = C; fa.sQ = (int64_t)S * C;
   fa.K = kv.K; fa.ldk = kv.ldk; fa.sK = kv.sK;
   fa.Vt = kv.Vt; fa.ldvt = kv.ldvt; fa.sVt = kv.sVt;
@@ -310,7 +312,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   TSD_TRY(launch_flash_attention(ctx, fa));
   half_t* tok3 = tok;  // tok (first residual) is dead after tok2 was produced
   a.p0 = ao;
-  TSD_TRY(g_linear(ctx, a, M, w.ca_out.w, w.ca_out.Kpad, C, C, w.ca_out.b, tok2, C, 0, tok3, C, nullptr, S));
+  TSD_TRY(g_linear(ctx, a, M, w.ca_out.w, w.ca_out.Kpad, C, C, w.ca_out.b, tok2, C, 0, tok3, C, nullptr, S, w.ca_out.w_tm));
   // ---- GEGLU feed-forward (:136-143) ----
   TSD_TRY(launch_layernorm(ctx, tok3, M, C, C, 1e-5f, ln, C, w.ln[2].w ? &w.ln[2] : nullptr));
   half_t* gg = arena_alloc<half_t>(ctx, M * 4 * C); CHECK_ALLOC(gg);
@@ -320,14 +322,14 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, 0, pre, 8 * C, nullptr, S));
     TSD_TRY(launch_geglu_erf_f16(ctx, pre, M, 4 * C, gg));
   } else {
-    TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S));
+    TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S, w.geglu1.w_tm));
   }
   half_t* tok4 = tok2;  // tok2 is dead after tok3
   CatSrc ag; ag.p0 = gg; ag.ld0 = 4 * C; ag.C0 = 4 * C;
-  TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C, nullptr, S));
+  TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C, nullptr, S, w.geglu2.w_tm));
   // ---- output 1x1 conv + long residual (:146) ----
   a.p0 = tok4;
-  TSD_TRY(g_linear(ctx, a, M, w.conv_out.w, w.conv_out.Ipad, C, C, w.conv_out.b, x.p, x.ld, 0, out.p, out.ld, &out, S));
+  TSD_TRY(g_linear(ctx, a, M, w.conv_out.w, w.conv_out.Ipad, C, C, w.conv_out.b, x.p, x.ld, 0, out.p, out.ld, &out, S, w.conv_out.w_tm));
   ctx->arena.release(mark);
   return TSD_OK;
 }

@@ -38,7 +38,8 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
               const CatSrc* skip_x = nullptr, const ConvW* skip_w = nullptr);  // + conv1x1(skip_x) fused as extra K (same resolution)
 // y[M][N] = A[M][K] . W^T (+bias) (+residual) ; A may be a concat view
 int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw, int N, int K, const float* bias,
-             const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat = nullptr, int rows_per_sample = 0);
+             const half_t* res, int ldr, int epi_extra, void* y, int ldy, Act* stat = nullptr, int rows_per_sample = 0,
+             const half_t* w_tm = nullptr);  // w_tm: K-tile-major copy of w ([K/64][N][64]) - used instead when given
 
 int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, const ResW& w, const float* tvec,
                int tld, Act& out);

@@ -25,6 +25,10 @@ static void model_invalidate_derived(tsd_model* m) {
   m->unet.conv_in_im2col = nullptr;
   m->vae.conv_in_im2col = nullptr;
   for (auto& r : m->unet.res) { r.conv1.w_tm = nullptr; r.conv2.w_tm = nullptr; }
+  for (auto& a : m->unet.attn) {
+    for (LinW* l : {&a.sa_in, &a.sa_out, &a.ca_q, &a.ca_out, &a.geglu1, &a.geglu2}) l->w_tm = nullptr;
+    a.conv_in.w_tm = nullptr; a.conv_out.w_tm = nullptr;
+  }
 }
 
 static size_t packed_bytes(const ParamSpec& p) {
@@ -158,6 +162,7 @@ extern "C" int tsd_model_mark_loaded(tsd_model* m) {
   return TSD_OK;
 }
 
+static bool tml_mib_on() { return !(getenv("TSD_LIN_W_TM") && atoi(getenv("TSD_LIN_W_TM")) == 0); }
 // derived device buffers (not part of the broadcast blob: every rank rebuilds them from the packed weights)
 static int model_build_derived(tsd_model* m) {
   tsd_ctx* ctx = m->ctx;
@@ -196,7 +201,20 @@ static int model_build_derived(tsd_model* m) {
     for (auto& r : m->unet.res)
       for (ConvW* c : {&r.conv1, &r.conv2})
         if (c->w && c->k == 3 && (size_t)c->Opad * 9 * c->Ipad * 2 >= (size_t)tm_mib << 20) { tm.push_back(c); tm_b += (((size_t)c->Opad * 9 * c->Ipad * 2) + 255) & ~size_t(255); }
-  if (el.empty() && !cin_ok && tm.empty()) return TSD_OK;
+  if (tm_mib > 0 && tml_mib_on())
+    for (auto& a : m->unet.attn)
+      if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
+        for (ConvW* c : {&a.conv_in, &a.conv_out})
+          if (c->w && c->k == 1 && c->Ipad % 64 == 0 && (size_t)c->Opad * c->Ipad * 2 >= (size_t)1 << 20) { tm.push_back(c); tm_b += (((size_t)c->Opad * c->Ipad * 2) + 255) & ~size_t(255); }
+  // ... and of the attention blocks' linear layers (TSD_LIN_W_TM MiB; the 64x64-level blocks read theirs through the fused kernels' streams)
+  static const int tml_mib = getenv("TSD_LIN_W_TM") ? atoi(getenv("TSD_LIN_W_TM")) : 1;  // measured: +0.4 % headline, +0.6 % full-size UNet (profiles/r03_lin_w_tile_major_ab.txt)
+  std::vector<LinW*> tml;
+  if (tml_mib > 0)
+    for (auto& a : m->unet.attn)
+      if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
+        for (LinW* l : {&a.sa_in, &a.sa_out, &a.ca_q, &a.ca_out, &a.geglu1, &a.geglu2})
+          if (l->w && l->Kpad % 64 == 0 && l->Kpad == l->K && (size_t)l->N * l->Kpad * 2 >= (size_t)tml_mib << 20) { tml.push_back(l); tm_b += (((size_t)l->N * l->Kpad * 2) + 255) & ~size_t(255); }
+  if (el.empty() && !cin_ok && tm.empty() && tml.empty()) return TSD_OK;
   const size_t tail_b = (attn_tail_stream_bytes() + 255) & ~size_t(255), head_b = (attn_head_stream_bytes() + 255) & ~size_t(255);
   const size_t each = tail_b + head_b, need = each * el.size() + cin_b + tm_b;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -234,9 +252,16 @@ static int model_build_derived(tsd_model* m) {
     for (size_t i = 0; i < tm.size() && r == TSD_OK; i++) {
       ConvW* c = tm[i];
       half_t* dst = (half_t*)(m->derived + off);
-      r = launch_pack_tile_major(ctx, c->w, c->Opad, 9 * c->Ipad, dst);
+      r = launch_pack_tile_major(ctx, c->w, c->Opad, c->k * c->k * c->Ipad, dst);
       if (r == TSD_OK) c->w_tm = dst;
-      off += (((size_t)c->Opad * 9 * c->Ipad * 2) + 255) & ~size_t(255);
+      off += (((size_t)c->Opad * c->k * c->k * c->Ipad * 2) + 255) & ~size_t(255);
+    }
+    for (size_t i = 0; i < tml.size() && r == TSD_OK; i++) {
+      LinW* l = tml[i];
+      half_t* dst = (half_t*)(m->derived + off);
+      r = launch_pack_tile_major(ctx, l->w, l->N, l->Kpad, dst);
+      if (r == TSD_OK) l->w_tm = dst;
+      off += (((size_t)l->N * l->Kpad * 2) + 255) & ~size_t(255);
     }
   }
   ctx->arena.planning = was_planning;
