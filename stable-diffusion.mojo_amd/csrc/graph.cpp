@@ -474,6 +474,7 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
     GemmArgs g;
     g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
     g.M = B * Tp; g.N = 2 * CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
+    if (u.kproj_all.w_tm) { g.Wt = u.kproj_all.w_tm; g.ldw = 64; g.w_kts = 2 * CK * 128; }
     g.Vt = vtc_all; g.vt_n0 = CK; g.vt_ld = Tp; g.vt_S = Tp; g.vt_sB = (int64_t)CK * Tp;
     TSD_TRY(launch_gemm(ctx, g));
   } else {
@@ -569,6 +570,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
     GemmArgs g;
     g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
     g.M = B * Tp; g.N = 2 * CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
+    if (u.kproj_all.w_tm) { g.Wt = u.kproj_all.w_tm; g.ldw = 64; g.w_kts = 2 * CK * 128; }
     g.Vt = vtc_all; g.vt_n0 = CK; g.vt_ld = Tp; g.vt_S = Tp; g.vt_sB = (int64_t)CK * Tp;
     TSD_TRY(launch_gemm(ctx, g));
   } else {

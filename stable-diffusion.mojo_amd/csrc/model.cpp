@@ -25,6 +25,8 @@ static void model_invalidate_derived(tsd_model* m) {
   m->unet.conv_in_im2col = nullptr;
   m->vae.conv_in_im2col = nullptr;
   for (auto& r : m->unet.res) { r.conv1.w_tm = nullptr; r.conv2.w_tm = nullptr; }
+  m->unet.conv4.w_tm = nullptr; m->unet.conv7.w_tm = nullptr; m->unet.kproj_all.w_tm = nullptr;
+  for (auto& cv : m->unet.conv) cv.w_tm = nullptr;
   for (auto& a : m->unet.attn) {
     for (LinW* l : {&a.sa_in, &a.sa_out, &a.ca_q, &a.ca_out, &a.geglu1, &a.geglu2}) l->w_tm = nullptr;
     a.conv_in.w_tm = nullptr; a.conv_out.w_tm = nullptr;
@@ -201,6 +203,12 @@ static int model_build_derived(tsd_model* m) {
     for (auto& r : m->unet.res)
       for (ConvW* c : {&r.conv1, &r.conv2})
         if (c->w && c->k == 3 && (size_t)c->Opad * 9 * c->Ipad * 2 >= (size_t)tm_mib << 20) { tm.push_back(c); tm_b += (((size_t)c->Opad * 9 * c->Ipad * 2) + 255) & ~size_t(255); }
+  if (tm_mib > 0) {  // downsampling / upsampling convs outside the residual blocks
+    for (ConvW* c : {&m->unet.conv4, &m->unet.conv7})
+      if (c->w && c->k == 3 && (size_t)c->Opad * 9 * c->Ipad * 2 >= (size_t)tm_mib << 20) { tm.push_back(c); tm_b += (((size_t)c->Opad * 9 * c->Ipad * 2) + 255) & ~size_t(255); }
+    for (auto& cv : m->unet.conv)
+      if (cv.w && cv.k == 3 && (size_t)cv.Opad * 9 * cv.Ipad * 2 >= (size_t)tm_mib << 20) { tm.push_back(&cv); tm_b += (((size_t)cv.Opad * 9 * cv.Ipad * 2) + 255) & ~size_t(255); }
+  }
   if (tm_mib > 0 && tml_mib_on())
     for (auto& a : m->unet.attn)
       if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
@@ -214,7 +222,13 @@ static int model_build_derived(tsd_model* m) {
       if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
         for (LinW* l : {&a.sa_in, &a.sa_out, &a.ca_q, &a.ca_out, &a.geglu1, &a.geglu2})
           if (l->w && l->Kpad % 64 == 0 && l->Kpad == l->K && (size_t)l->N * l->Kpad * 2 >= (size_t)tml_mib << 20) { tml.push_back(l); tm_b += (((size_t)l->N * l->Kpad * 2) + 255) & ~size_t(255); }
-  if (el.empty() && !cin_ok && tm.empty() && tml.empty()) return TSD_OK;
+  LinW* kv = nullptr;  // k_proj | v_proj rows of all blocks (adjacent in the blob: the fused context projection of g_unet_forward)
+  if (tml_mib > 0 && m->unet.kproj_all.w && m->unet.vproj_all.w == m->unet.kproj_all.w + (int64_t)m->unet.kproj_all.N * m->unet.kproj_all.Kpad &&
+      m->unet.kproj_all.Kpad % 64 == 0 && m->unet.vproj_all.N == m->unet.kproj_all.N) {
+    kv = &m->unet.kproj_all;
+    tm_b += (((size_t)2 * kv->N * kv->Kpad * 2) + 255) & ~size_t(255);
+  }
+  if (el.empty() && !cin_ok && tm.empty() && tml.empty() && !kv) return TSD_OK;
   const size_t tail_b = (attn_tail_stream_bytes() + 255) & ~size_t(255), head_b = (attn_head_stream_bytes() + 255) & ~size_t(255);
   const size_t each = tail_b + head_b, need = each * el.size() + cin_b + tm_b;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -255,6 +269,12 @@ static int model_build_derived(tsd_model* m) {
       r = launch_pack_tile_major(ctx, c->w, c->Opad, c->k * c->k * c->Ipad, dst);
       if (r == TSD_OK) c->w_tm = dst;
       off += (((size_t)c->Opad * c->k * c->k * c->Ipad * 2) + 255) & ~size_t(255);
+    }
+    if (kv && r == TSD_OK) {
+      half_t* dst = (half_t*)(m->derived + off);
+      r = launch_pack_tile_major(ctx, kv->w, 2 * kv->N, kv->Kpad, dst);
+      if (r == TSD_OK) kv->w_tm = dst;
+      off += (((size_t)2 * kv->N * kv->Kpad * 2) + 255) & ~size_t(255);
     }
     for (size_t i = 0; i < tml.size() && r == TSD_OK; i++) {
       LinW* l = tml[i];
