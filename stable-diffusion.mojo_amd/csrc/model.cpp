@@ -197,6 +197,10 @@ static int model_build_derived(tsd_model* m) {
   const size_t cin_b = cin_ok ? ((size_t)cin.Opad * 64 * sizeof(half_t) + 255) & ~size_t(255) : 0;
   // weight-heavy 3x3 convs (>= TSD_CONV_W_TM MiB of weights; 0 = off): K-tile-major copies
   static const int tm_mib = getenv("TSD_CONV_W_TM") ? atoi(getenv("TSD_CONV_W_TM")) : 2;  // measured: +0.3 % headline, +0.6 % full-size UNet (profiles/r03_conv_w_tile_major_ab.txt)
+  // linear layers / 1x1 convs: TSD_LIN_W_TM = 0 turns them off, TSD_LIN_W_TM_KIB sets the size threshold (default 1 MiB; with 512 KiB the
+  // 800-KB 640 x 640 projections of the 32x32 level join in: measured equal, 205.65 vs 205.60 steps/s)
+  static const int tml_kib = getenv("TSD_LIN_W_TM_KIB") ? atoi(getenv("TSD_LIN_W_TM_KIB")) : 1024;
+  const size_t tml_bytes = (size_t)(tml_kib > 0 ? tml_kib : 1024) << 10;
   std::vector<ConvW*> tm;
   size_t tm_b = 0;
   if (tm_mib > 0)
@@ -213,7 +217,7 @@ static int model_build_derived(tsd_model* m) {
     for (auto& a : m->unet.attn)
       if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
         for (ConvW* c : {&a.conv_in, &a.conv_out})
-          if (c->w && c->k == 1 && c->Ipad % 64 == 0 && (size_t)c->Opad * c->Ipad * 2 >= (size_t)1 << 20) { tm.push_back(c); tm_b += (((size_t)c->Opad * c->Ipad * 2) + 255) & ~size_t(255); }
+          if (c->w && c->k == 1 && c->Ipad % 64 == 0 && (size_t)c->Opad * c->Ipad * 2 >= tml_bytes) { tm.push_back(c); tm_b += (((size_t)c->Opad * c->Ipad * 2) + 255) & ~size_t(255); }
   // ... and of the attention blocks' linear layers (TSD_LIN_W_TM MiB; the 64x64-level blocks read theirs through the fused kernels' streams)
   static const int tml_mib = getenv("TSD_LIN_W_TM") ? atoi(getenv("TSD_LIN_W_TM")) : 1;  // measured: +0.4 % headline, +0.6 % full-size UNet (profiles/r03_lin_w_tile_major_ab.txt)
   std::vector<LinW*> tml;
@@ -221,7 +225,7 @@ static int model_build_derived(tsd_model* m) {
     for (auto& a : m->unet.attn)
       if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
         for (LinW* l : {&a.sa_in, &a.sa_out, &a.ca_q, &a.ca_out, &a.geglu1, &a.geglu2})
-          if (l->w && l->Kpad % 64 == 0 && l->Kpad == l->K && (size_t)l->N * l->Kpad * 2 >= (size_t)tml_mib << 20) { tml.push_back(l); tm_b += (((size_t)l->N * l->Kpad * 2) + 255) & ~size_t(255); }
+          if (l->w && l->Kpad % 64 == 0 && l->Kpad == l->K && (size_t)l->N * l->Kpad * 2 >= tml_bytes) { tml.push_back(l); tm_b += (((size_t)l->N * l->Kpad * 2) + 255) & ~size_t(255); }
   LinW* kv = nullptr;  // k_proj | v_proj rows of all blocks (adjacent in the blob: the fused context projection of g_unet_forward)
   if (tml_mib > 0 && m->unet.kproj_all.w && m->unet.vproj_all.w == m->unet.kproj_all.w + (int64_t)m->unet.kproj_all.N * m->unet.kproj_all.Kpad &&
       m->unet.kproj_all.Kpad % 64 == 0 && m->unet.vproj_all.N == m->unet.kproj_all.N) {
