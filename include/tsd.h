@@ -43,7 +43,9 @@ typedef enum tsd_status {
   TSD_E_ALLOC = -3,
   TSD_E_HIP = -4, /* HIP runtime error or no usable GPU */
   TSD_E_RCCL = -5,
-  TSD_E_STATE = -6 /* call order violated (e.g. forward before weights set) */
+  TSD_E_STATE = -6, /* call order violated (e.g. forward before weights set) */
+  TSD_E_NONFINITE = -7 /* inf / NaN reached a tensor that leaves the device (fp16 activation overflow or non-finite input):
+                        * reported by the next synchronisation point, see tsd_debug_nonfinite_count */
 } tsd_status;
 
 typedef struct tsd_ctx tsd_ctx;         /* one per GPU: device, stream, workspace arena */
@@ -272,16 +274,26 @@ int tsd_dist_broadcast_weights(tsd_model* m, int root); /* ncclBroadcast of the 
 int tsd_dist_finalize(tsd_ctx* ctx);
 
 /* ---- debug / tuning -------------------------------------------------------------------- */
-/* Time one GEMM (conv = 0: M = B*H*W, K = Cin) or conv3x3 problem on synthetic device data with tile
- * configuration `cfg` (< 0: dispatcher's choice); average ms per launch over `iters` launches. */
+/* Every switch below belongs to ONE context: the library keeps no process-global mutable state besides the thread-local error
+ * string, so two contexts (one per GPU, each driven by its own host thread) may run different settings side by side.  The
+ * TSD_* environment variables named here are read once, by tsd_ctx_create, into that context.  A denoise session sizes its
+ * workspace for the settings active at upload(): after a tsd_debug_set_* call on its context, step() / decode() fail with
+ * TSD_E_STATE until upload() is called again. */
 /* split-K hand-offs that timed out or paired blocks on different XCDs since the context was created (must be 0);
  * 1 when workgroups map to XCDs round-robin (the precondition of the L2-local split-K hand-off). */
 int tsd_debug_splitk_errors(tsd_ctx* ctx);
 int tsd_debug_xcd_round_robin(void);
+/* Non-finite values (inf / NaN) written to caller-visible tensors on this context since the last report: the path stores
+ * activations as fp16 (|x| <= 65504) where the reference computes in fp32 (helpers/utils.mojo:12-15), so an overflow is possible
+ * and must never be silent.  Every kernel that produces a tensor that leaves the device counts what it writes; the synchronous
+ * entry points, tsd_ctx_synchronize and the session downloads return TSD_E_NONFINITE when the count is non-zero (and clear it).
+ * This call reads the count without failing (reset != 0 clears it); < 0 on error.  Synchronises the context's stream. */
+int tsd_debug_nonfinite_count(tsd_ctx* ctx, int reset);
 /* A/B switch for the fused attention-block kernels of the 64x64 level (kernels_chain.hip): 0 = op-by-op graph, 1 = fused
- * (default; TSD_CHAIN=0 in the environment has the same effect).  Returns the previous setting.  Sessions sized their
- * workspace for the graph active at upload(): switch before creating the session. */
-int tsd_debug_set_fused_attention(int on);
+ * (default; TSD_CHAIN=0 in the environment has the same effect).  Returns the previous setting. */
+int tsd_debug_set_fused_attention(tsd_ctx* ctx, int on);
+/* Time one GEMM (conv = 0: M = B*H*W, K = Cin) or conv3x3 problem on synthetic device data with tile
+ * configuration `cfg` (< 0: dispatcher's choice); average ms per launch over `iters` launches. */
 int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups, int cfg,
                          int iters, float* ms);
 
@@ -298,20 +310,20 @@ int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset);
  * Both compute every row with the same instruction sequence: bitwise equal results as long as no workgroup takes the exact
  * repeat (there the repeat and the reference moves are decided per workgroup / per wave, i.e. over different row sets).  The
  * default choice depends on the layer shape only, never on the batch.  Returns the previous mode. */
-int tsd_debug_set_attn_qb(int mode);
+int tsd_debug_set_attn_qb(tsd_ctx* ctx, int mode);
 /* Self-attention (Sq == Sk): the optimistic softmax reference is max(row maximum of key tile 0, row maximum over the query's
  * own 32-key block) + headroom; on = 0 restores the tile-0-only reference (to measure what the second reference saves on
  * peaked score distributions).  Returns the previous setting. */
-int tsd_debug_set_attn_diag(int on);
+int tsd_debug_set_attn_diag(tsd_ctx* ctx, int on);
 /* Residual blocks whose skip path is a 1x1 convolution at the block's own resolution (diffusion.mojo:70-72, vae.mojo:65-67) run it
  * inside the second 3x3 convolution as extra K (on = 1, default); on = 0 runs it as its own GEMM + residual add (the round-2 path,
  * kept for A/B and for the equivalence test).  Returns the previous setting. */
-int tsd_debug_set_res_fuse_skip(int on);
+int tsd_debug_set_res_fuse_skip(tsd_ctx* ctx, int on);
 /* Self-attention input projection (helpers/attention.mojo:29-31): q | k (token-major) and V^T (channel-major, what the attention
  * kernel reads) come from ONE GEMM over in_proj's 3C rows whose tiles beyond column 2C store transposed (on = 1, default; needs
  * H*W % 32 == 0); on = 0 runs the q/k GEMM and the swapped-operand V^T GEMM as two launches.  Environment: TSD_QKV_FUSE.  Returns
  * the previous setting. */
-int tsd_debug_set_qkv_fuse(int on);
+int tsd_debug_set_qkv_fuse(tsd_ctx* ctx, int on);
 /* What this board sustains on the matrix pipe: a register-resident dense fp16 MFMA loop (no LDS, no memory) run for about
  * `ms_target` ms at 4 waves per SIMD; reports the achieved TFLOP/s and the shader clock (GHz) during the run.  The nominal
  * dense peak assumes the boost clock; under matrix-pipe load the board's power limit sets the clock. */

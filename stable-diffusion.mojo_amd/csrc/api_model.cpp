@@ -29,7 +29,7 @@ int run_model(tsd_model* m, F&& fn) {
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (r != TSD_OK) return r;
   if (e != hipSuccess) TSD_FAIL(TSD_E_HIP, "stream synchronize failed: %s", hipGetErrorString(e));
-  return ctx_check_splitk(ctx);
+  return ctx_check_status(ctx);
 }
 }  // namespace
 
@@ -137,6 +137,7 @@ struct tsd_session {
   std::vector<int> timesteps;
   bool uploaded = false, has_noise = false;
   size_t plan_unet = 0, plan_dec = 0;
+  unsigned opt_gen = 0;  // generation of the context's options the workspace was sized for (upload)
 };
 
 static void build_schedule(tsd_session* s) {
@@ -266,6 +267,7 @@ extern "C" int tsd_session_upload(tsd_session* s, const float* latents, const fl
   a.planning = false; a.top = 0; a.peak = 0;
   if (r != TSD_OK) return r;
   TSD_TRY(ctx_reserve_arena(ctx, need));
+  s->opt_gen = ctx->opt.gen;
   s->uploaded = true;
   return TSD_OK;
 }
@@ -288,6 +290,7 @@ static void ddpm_coeffs(const tsd_session* s, int t, float* sa, float* sb, float
 extern "C" int tsd_session_step(tsd_session* s, int i) {
   NOTNULL(s);
   if (!s->uploaded) TSD_FAIL(TSD_E_STATE, "session: upload() before step()");
+  if (s->opt_gen != s->ctx->opt.gen) TSD_FAIL(TSD_E_STATE, "session: a tsd_debug_set_* call changed this context's options after upload() sized the workspace; upload() again");
   if (i < 0 || i >= (int)s->timesteps.size()) TSD_FAIL(TSD_E_ARG, "session: step %d out of range", i);
   tsd_ctx* ctx = s->ctx;
   const int B = s->B, L = s->L, Bu = s->cfg ? 2 * B : B;
@@ -330,6 +333,7 @@ extern "C" int tsd_session_decode(tsd_session* s) {
   NOTNULL(s);
   if (!s->dec) TSD_FAIL(TSD_E_STATE, "session: created without a decoder");
   if (!s->uploaded) TSD_FAIL(TSD_E_STATE, "session: upload() before decode()");
+  if (s->opt_gen != s->ctx->opt.gen) TSD_FAIL(TSD_E_STATE, "session: a tsd_debug_set_* call changed this context's options after upload() sized the workspace; upload() again");
   s->ctx->arena.top = 0;
   int r = g_decoder_forward(s->dec, s->latents, s->B, s->L, s->images);
   s->ctx->arena.top = 0;
@@ -340,7 +344,7 @@ extern "C" int tsd_session_download_latents(tsd_session* s, float* latents) {
   NOTNULL(s); NOTNULL(latents);
   HIP_TRY(hipMemcpyAsync(latents, s->latents, (size_t)s->B * 4 * s->L * s->L * 4, hipMemcpyDeviceToHost, s->ctx->stream));
   HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-  TSD_TRY(ctx_check_splitk(s->ctx));
+  TSD_TRY(ctx_check_status(s->ctx));
   return TSD_OK;
 }
 
@@ -357,7 +361,7 @@ extern "C" int tsd_session_download_images(tsd_session* s, int rescale_0_255, fl
   }
   HIP_TRY(hipMemcpyAsync(images, src, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return ctx_check_splitk(ctx);
+  return ctx_check_status(ctx);
 }
 
 // ---- RCCL weight broadcast over xGMI ---------------------------------------

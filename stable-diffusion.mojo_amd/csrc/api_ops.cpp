@@ -87,7 +87,7 @@ int run_op(tsd_ctx* ctx, F&& fn) {
     return r;
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return TSD_OK;
+  return ctx_check_status(ctx);  // split-K hand-off time-outs, non-finite outputs (fp16 overflow): never silent
 }
 }  // namespace
 

@@ -47,14 +47,47 @@ struct Arena {
   }
 };
 
+// Every tuning / A-B switch of the library.  Read from the environment ONCE, by tsd_ctx_create, into the context that the launches
+// run on: no dispatch code calls getenv and no switch is process-global, so two contexts (one per GPU, one host thread each - SURVEY.md
+// section 8b "Threading") can run different settings side by side.  The tsd_debug_set_* entry points change ONE context and bump its
+// `gen`; a denoise session remembers the generation it sized its workspace for (api_model.cpp).  Defaults = the measured optimum.
+struct TsdOptions {
+  // graph shape (graph.cpp)
+  int qkv_fuse = 1;        // TSD_QKV_FUSE: q | k | V^T (and the context K | V^T of all blocks) from ONE GEMM with a transposed tail
+  int res_fuse_skip = 1;   // TSD_RES_FUSE_SKIP: residual block's 1x1 skip convolution as extra K of its second 3x3 convolution
+  int gn_composite = 1;    // TSD_GN_COMPOSITE: GroupNorm over a channel concat from the two producers' partial statistics
+  int conv_in_im2col = 1;  // TSD_CONV_IN_IM2COL: the 4-channel input convolution as one im2col K tile
+  int chain = 1;           // TSD_CHAIN: fused head / tail kernels of the 64x64-level attention blocks
+  // derived weight copies (model.cpp; read when a model's derived buffers are built)
+  int conv_w_tm_mib = 2, lin_w_tm = 1, lin_w_tm_kib = 1024;  // TSD_CONV_W_TM, TSD_LIN_W_TM, TSD_LIN_W_TM_KIB
+  // flash attention (kernels_attn.hip)
+  int attn_qb = 2;         // TSD_ATTN_QB: d = 40, 32-query blocks per wave where the key loop is long
+  int attn_qb_force = 0;   // tsd_debug_set_attn_qb: 0 = by shape, 1 / 2 = always
+  int attn_diag = 1;       // tsd_debug_set_attn_diag: second optimistic reference (the query's own key block)
+  int attn_xcd = 0;        // TSD_ATTN_XCD: XCD-aware (head, query tile) map
+  // GEMM / conv dispatch (kernels_gemm.hip)
+  int xcdn = 0, conv_halo = 0, splitk = 1, splitk_mink = 4096, splitk_tiles = 256, splitk_small = 8, splitk_wide = 1, splitk_ring4 = 0,
+      splitk_big = 0, sk_cfg = 5, thin_cfg = 0, tune = 15;
+  int force_cfg = -1;      // tsd_debug_gemm_bench / _check: tile configuration forced for the launches of this context
+  int sk_big_graph = 0;    // slices of the long-K split launches asked for by the graph being enqueued (gemm_set_splitk_big)
+  char cfg_override[512] = "";  // TSD_GEMM_CFG_OVERRIDE
+  int gn_apply_mult = 2;   // TSD_GN_APPLY_MULT
+  int debug_occ = 0;       // TSD_DEBUG_OCC
+  int bench_wrot = 1, bench_epi = 0, bench_altcfg = -1, gemm_ts = 0;  // microbenchmark only (tsd_debug_gemm_bench)
+  unsigned gen = 0;        // bumped by every tsd_debug_set_* call on this context
+};
+void options_from_env(TsdOptions& o);
+
 struct tsd_ctx {
   int device = 0;
+  TsdOptions opt;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Arena arena;
   int* sk_flags = nullptr;  // 4096 zeroed ints, allocated on first use: one split-K arrival flag per (slice, tile) holding the
                             // epoch of the launch that published it and, at [4095], a sticky count of hand-offs that timed out
   unsigned sk_epoch = 0;    // split-K launches so far on this context (the flag value of the next launch; never 0)
+  int* status = nullptr;    // 16 zeroed ints: [0] non-finite values written to caller-visible tensors since the last report (kernels_elementwise.hip), [2] flash-attention workgroups that repeated exactly
   half_t* zeros = nullptr;  // 4 KiB: [0,2048) zeros (padded im2col taps / head dims); [2048,2176) fp16 ones
   void* staging = nullptr;  // device staging for host<->device copies
   size_t staging_cap = 0;
@@ -102,6 +135,9 @@ int ctx_reserve_arena(tsd_ctx* ctx, size_t bytes);
 // call after a stream synchronize: TSD_E_STATE if any split-K hand-off of this context ever timed out (results since then
 // cannot be trusted)
 int ctx_check_splitk(tsd_ctx* ctx);
+// ... and TSD_E_NONFINITE if inf / NaN reached a caller-visible tensor since the last report (count cleared once reported).  Every
+// synchronisation point of the ABI calls this one; it includes ctx_check_splitk.
+int ctx_check_status(tsd_ctx* ctx);
 int ctx_reserve_staging(tsd_ctx* ctx, size_t bytes);
 
 // ---- device tensor views (NHWC fp16 activations) ---------------------------------------
@@ -189,9 +225,9 @@ struct GemmArgs {
   int rows_per_sample_hint = 0;
 };
 int launch_gemm(tsd_ctx* ctx, const GemmArgs& a);
-// slices of the long-K split launches (K >= 8192, 16x16 level) for the graph being enqueued on this thread; returns the previous value
-int gemm_set_splitk_big(int ways);
-int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups);  // 0: not available
+// slices of the long-K split launches (K >= 8192, 16x16 level) for the graph being enqueued on this context; returns the previous value
+int gemm_set_splitk_big(tsd_ctx* ctx, int ways);
+int gemm_gnstats_slabs(const tsd_ctx* ctx, int M, int N, int K, int batch, int conv, int rows_per_sample, int groups);  // 0: not available
 
 // ---- other kernel launchers -----------------------------------------------------------
 // layout / elementwise (kernels_elementwise.hip)
@@ -288,7 +324,7 @@ struct AttnTailArgs {
   float scale = 1.f, eps = 1e-5f;
   float* gn_part = nullptr; int gn_nslab = 0;  // GroupNorm(32) statistics of the output, one slab per 32 rows
 };
-bool attn_tail_supported(int C, int d, int heads, int T, int64_t M, int S);
+bool attn_tail_supported(const tsd_ctx* ctx, int C, int d, int heads, int T, int64_t M, int S);
 int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a);
 size_t attn_tail_stream_bytes();
 // fused head of the same block (kernels_chain.hip): GroupNorm-apply, 1x1 conv_in (-> tok), LayerNorm, q / k projections and

@@ -24,12 +24,12 @@ Act act_alloc_gn(tsd_ctx* ctx, int B, int H, int W, int C, int groups) {
 
 // ask the GEMM/conv that writes `dst` to emit the statistics of the GroupNorm that will read it (EPI_GNSTATS); a tile
 // geometry that cannot do it leaves dst->gn_part NULL and the consumer runs its own statistics pass.
-static void gn_emit(GemmArgs& g, Act* dst, int rows_per_sample) {
+static void gn_emit(const tsd_ctx* ctx, GemmArgs& g, Act* dst, int rows_per_sample) {
   if (!dst || !dst->gn_buf || dst->gn_groups <= 0 || g.N != dst->C || (g.epi & (EPI_OUT_F32 | EPI_GEGLU))) return;
-  const int ns = gemm_gnstats_slabs(g.M, g.N, g.K, g.batch, g.conv, rows_per_sample, dst->gn_groups);
+  const int ns = gemm_gnstats_slabs(ctx, g.M, g.N, g.K, g.batch, g.conv, rows_per_sample, dst->gn_groups);
   // up to 128 slabs the apply blocks (or k_gn_finalize) reduce them directly; beyond 256 (the VAE's 128^2 ... 512^2 images)
   // launch_groupnorm pre-reduces them to 64 chunks per sample (k_gn_prereduce) - either way no statistics pass over the tensor
-  if (ns <= 0 || ns > ceil_div(rows_per_sample, 32) || (ns > 128 && ns <= 256) || dst->gn_groups > 256) return;
+  if (ns <= 0 || ns > ceil_div(rows_per_sample, 32) || (ns > 128 && ns <= 256) || (ns > 256 && dst->gn_groups > 256)) return;  // the 256-group limit is k_gn_prereduce's
   g.epi |= EPI_GNSTATS;
   g.gn_part = dst->gn_buf; g.gn_groups = dst->gn_groups; g.gn_rows_per_sample = rows_per_sample; g.gn_nslab = ns;
   dst->gn_part = dst->gn_buf; dst->gn_nslab = ns;
@@ -68,7 +68,7 @@ int g_conv3x3(tsd_ctx* ctx, const Act& x, const ConvW& w, int stride, int pad, i
   }
   g.C = y; g.ldc = ldy;
   g.rows_per_sample_hint = Ho * Wo;
-  gn_emit(g, stat, Ho * Wo);
+  gn_emit(ctx, g, stat, Ho * Wo);
   return launch_gemm(ctx, g);
 }
 
@@ -84,28 +84,27 @@ int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw,
   if (res) { g.epi |= EPI_RESIDUAL; g.R = res; g.ldr = ldr; }
   g.C = y; g.ldc = ldy;
   g.rows_per_sample_hint = rows_per_sample;
-  gn_emit(g, stat, rows_per_sample);
+  gn_emit(ctx, g, stat, rows_per_sample);
   return launch_gemm(ctx, g);
 }
 
 // q/k/v projection as one GEMM with a transposed tail (GemmArgs::Vt): whole 32-token passes per sample, V columns on a tile boundary
-static int g_qkv_fuse = -1;
-extern "C" int tsd_debug_set_qkv_fuse(int on) {
-  const int prev = g_qkv_fuse < 0 ? 1 : g_qkv_fuse;
-  if (on == 0 || on == 1) g_qkv_fuse = on;
+// The graph-shape switches live in the context (TsdOptions); a setter changes THAT context only and returns the old value.
+extern "C" int tsd_debug_set_qkv_fuse(tsd_ctx* ctx, int on) {
+  if (!ctx) return TSD_E_ARG;
+  const int prev = ctx->opt.qkv_fuse;
+  if (on == 0 || on == 1) { ctx->opt.qkv_fuse = on; ctx->opt.gen++; }
   return prev;
 }
-static bool qkv_fused_ok(int S, int Sp, int C) {
-  if (g_qkv_fuse < 0) g_qkv_fuse = getenv("TSD_QKV_FUSE") ? atoi(getenv("TSD_QKV_FUSE")) : 1;
+static bool qkv_fused_ok(const tsd_ctx* ctx, int S, int Sp, int C) {
   const int BN = ((3 * C) % 160 == 0) ? 160 : 128;
-  return g_qkv_fuse && S % 32 == 0 && Sp == S && (2 * C) % BN == 0;
+  return ctx->opt.qkv_fuse && S % 32 == 0 && Sp == S && (2 * C) % BN == 0;
 }
 
 // context K / V^T of all attention blocks from one GEMM: the concatenated v_proj rows follow the k_proj rows in the blob
-static bool ctx_kv_fused_ok(const UNetW& u, int Tp) {
-  if (g_qkv_fuse < 0) g_qkv_fuse = getenv("TSD_QKV_FUSE") ? atoi(getenv("TSD_QKV_FUSE")) : 1;
+static bool ctx_kv_fused_ok(const tsd_ctx* ctx, const UNetW& u, int Tp) {
   const int CK = u.kproj_all.N;
-  return g_qkv_fuse && Tp % 8 == 0 && CK % 160 == 0 && u.vproj_all.N == CK && u.vproj_all.Kpad == u.kproj_all.Kpad &&
+  return ctx->opt.qkv_fuse && Tp % 8 == 0 && CK % 160 == 0 && u.vproj_all.N == CK && u.vproj_all.Kpad == u.kproj_all.Kpad &&
          u.vproj_all.w == u.kproj_all.w + (int64_t)CK * u.kproj_all.Kpad;
 }
 
@@ -116,10 +115,10 @@ static NormSrc norm_src(const CatSrc& x, int C) {
   return s;
 }
 
-static int g_res_fuse_skip = -1;  // -1: read TSD_RES_FUSE_SKIP on first use (default on)
-extern "C" int tsd_debug_set_res_fuse_skip(int on) {
-  const int prev = g_res_fuse_skip < 0 ? 1 : g_res_fuse_skip;
-  if (on == 0 || on == 1) g_res_fuse_skip = on;
+extern "C" int tsd_debug_set_res_fuse_skip(tsd_ctx* ctx, int on) {
+  if (!ctx) return TSD_E_ARG;
+  const int prev = ctx->opt.res_fuse_skip;
+  if (on == 0 || on == 1) { ctx->opt.res_fuse_skip = on; ctx->opt.gen++; }
   return prev;
 }
 
@@ -139,8 +138,7 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   // channel concat (diffusion.mojo:253-270): the norm's groups are sums of whole groups of the two producers' statistics when both
   // were emitted at one granularity that divides the concat's group size - no statistics pass over the concatenated tensor
   GnComposite gc;
-  static const int comp_on = getenv("TSD_GN_COMPOSITE") ? atoi(getenv("TSD_GN_COMPOSITE")) : 1;
-  if (comp_on && x.p1 && cin == x.C0 + x.C1 && x.gn_part0 && x.gn_part1 && x.gn_groups0 > 0 && x.gn_groups1 > 0 &&
+  if (ctx->opt.gn_composite && x.p1 && cin == x.C0 + x.C1 && x.gn_part0 && x.gn_part1 && x.gn_groups0 > 0 && x.gn_groups1 > 0 &&
       x.gn_nslab0 == x.gn_nslab1 && x.gn_nslab0 > 0 && x.C0 % x.gn_groups0 == 0 && x.C1 % x.gn_groups1 == 0 && cin % w.groups == 0) {
     const int cf = x.C0 / x.gn_groups0, cpg = cin / w.groups;
     if (cf == x.C1 / x.gn_groups1 && cpg % cf == 0) {
@@ -158,8 +156,7 @@ int g_resblock(tsd_ctx* ctx, const CatSrc& x, int B, int Hin, int Win, int ups, 
   // Skip path `x + ...` / `conv1x1(x) + ...` (diffusion.mojo:70-72, vae.mojo:65-67).  At the block's own resolution the 1x1 convolution
   // is folded into the second 3x3 convolution as extra K (one launch and one residual read less, and the products run at the
   // big convolution's rate); behind an upsample it stays a GEMM at the input resolution (a quarter of the rows).
-  if (g_res_fuse_skip < 0) g_res_fuse_skip = getenv("TSD_RES_FUSE_SKIP") ? atoi(getenv("TSD_RES_FUSE_SKIP")) : 1;
-  if (w.has_skip && !ups && g_res_fuse_skip > 0 && w.skip.k == 1 && w.skip.Ipad % 64 == 0 && w.skip.Ipad == cin &&
+  if (w.has_skip && !ups && ctx->opt.res_fuse_skip > 0 && w.skip.k == 1 && w.skip.Ipad % 64 == 0 && w.skip.Ipad == cin &&
       !(x.p1 && cin > x.C0 && (x.C0 % 64))) {
     TSD_TRY(g_conv3x3(ctx, h3, w.conv2, 1, 1, 1, 0, nullptr, 0, nullptr, 0, false, out.p, out.ld, &out, &x, &w.skip));
     ctx->arena.release(mark);
@@ -198,7 +195,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   // The block's head - GroupNorm-apply, conv_in, LayerNorm, q / k / V^T projections - is local to a token row as well once
   // the GroupNorm statistics are known (the producer's epilogue emitted them): one kernel at the 64x64 level.
   const half_t* head_stream = w.head_stream;
-  const bool head_ok = Sp == S && x.ld % 8 == 0 && attn_tail_supported(C, d, Hh, 1, M, S) && attn_head_weights_ok(w);
+  const bool head_ok = Sp == S && x.ld % 8 == 0 && attn_tail_supported(ctx, C, d, Hh, 1, M, S) && attn_head_weights_ok(w);
   if (head_ok && !head_stream && !pre) {  // block-level entry: no model, pack on the fly
     half_t* hs = arena_alloc<half_t>(ctx, (int64_t)attn_head_stream_bytes() / 2); CHECK_ALLOC(hs);
     TSD_TRY(launch_attn_head_pack(ctx, w.conv_in.w, w.conv_in.Ipad, w.sa_in.w, w.sa_in.Kpad, hs));
@@ -223,7 +220,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
     // ---- self attention (:122-126) ----
     TSD_TRY(launch_layernorm(ctx, tok, M, C, C, 1e-5f, ln, C, w.ln[0].w ? &w.ln[0] : nullptr));
     a.p0 = ln; a.ld0 = C; a.C0 = C;
-    if (qkv_fused_ok(S, Sp, C)) {  // q | k token-major and V^T channel-major from ONE GEMM over in_proj's 3C rows (transposed tail)
+    if (qkv_fused_ok(ctx, S, Sp, C)) {  // q | k token-major and V^T channel-major from ONE GEMM over in_proj's 3C rows (transposed tail)
       GemmArgs g;
       g.A0 = ln; g.lda0 = C; g.Wt = w.sa_in.w; g.ldw = w.sa_in.Kpad; g.M = (int)M; g.N = 3 * C; g.K = C;
       if (w.sa_in.w_tm) { g.Wt = w.sa_in.w_tm; g.ldw = 64; g.w_kts = 3 * C * 128; }
@@ -275,7 +272,7 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   // op-by-op path).
   // The block-level entry (no model) packs the stream into the workspace on the fly.
   const half_t* tail_stream = w.tail_stream;
-  const bool tail_ok = attn_tail_supported(C, d, Hh, T, M, S) && attn_tail_weights_ok(w);
+  const bool tail_ok = attn_tail_supported(ctx, C, d, Hh, T, M, S) && attn_tail_weights_ok(w);
   if (tail_ok && !tail_stream && !pre) {
     half_t* ts = arena_alloc<half_t>(ctx, (int64_t)attn_tail_stream_bytes() / 2); CHECK_ALLOC(ts);
     TSD_TRY(launch_attn_tail_pack(ctx, w.sa_out.w, w.sa_out.Kpad, w.ca_q.w, w.ca_q.Kpad, w.ca_out.w, w.ca_out.Kpad, w.geglu1.w,
@@ -370,7 +367,7 @@ int g_attn_core(tsd_ctx* ctx, const AttnArgs& fa) {
 // q,k (token-major [B*S][2C]) and v^T ([B][C][Sp]) from a fused in_proj (3C, C) (helpers/attention.mojo:29)
 int g_qkv_proj(tsd_ctx* ctx, const half_t* x, int B, int S, int C, const LinW& in_proj, half_t* qk, half_t* vt,
                int Sp) {
-  if (qkv_fused_ok(S, Sp, C) && in_proj.Kpad == C) {
+  if (qkv_fused_ok(ctx, S, Sp, C) && in_proj.Kpad == C) {
     GemmArgs g;
     g.A0 = x; g.lda0 = C; g.Wt = in_proj.w; g.ldw = in_proj.Kpad; g.M = B * S; g.N = 3 * C; g.K = in_proj.Kpad;
     if (in_proj.b) { g.epi = EPI_BIAS_N; g.bias = in_proj.b; }
@@ -424,9 +421,9 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
 int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, int T, int Tp, const float* temb, int B,
                    int L, float* eps_out_chw, bool eps_nhwc) {
   if (is_full_unet_kind(m->kind)) {
-    const int prev = gemm_set_splitk_big(4);  // measured for this graph at its batch of 4 (BASELINE configs[4]): +4.3 %
+    const int prev = gemm_set_splitk_big(m->ctx, 4);  // measured for this graph at its batch of 4 (BASELINE configs[4]): +4.3 %
     const int r = g_unet_full_forward(m, latents_chw, ctx16, T, Tp, temb, B, L, eps_out_chw, eps_nhwc);
-    gemm_set_splitk_big(prev);
+    gemm_set_splitk_big(m->ctx, prev);
     return r;
   }
   tsd_ctx* ctx = m->ctx;
@@ -444,8 +441,7 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   // ---- input ----
   // `Conv2D(4, 320, 3)` (diffusion.mojo:236): the latent's 4 channels padded to a 64-channel NHWC tensor made the implicit GEMM walk
   // nine K tiles with 4 of 64 columns live; gathered to im2col rows at the boundary (36 of 64 columns live) it is ONE K tile
-  static const int im2col_on = getenv("TSD_CONV_IN_IM2COL") ? atoi(getenv("TSD_CONV_IN_IM2COL")) : 1;
-  const bool in_im2col = im2col_on && u.conv_in_im2col && u.conv1.I == 4;
+  const bool in_im2col = ctx->opt.conv_in_im2col && u.conv_in_im2col && u.conv1.I == 4;
   Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
   if (in_im2col) TSD_TRY(launch_chw_f32_to_im2col3x3_f16(ctx, latents_chw, B, 4, L, L, x0.p));
   else TSD_TRY(launch_chw_f32_to_nhwc_f16(ctx, latents_chw, B, 4, L, L, 4, 1.f, x0.p, 64));
@@ -470,7 +466,7 @@ int g_unet_forward(tsd_model* m, const float* latents_chw, const half_t* ctx16, 
   const int CK = u.kproj_all.N;
   half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
   half_t* vtc_all = arena_alloc<half_t>(ctx, (int64_t)B * CK * Tp); CHECK_ALLOC(vtc_all);
-  if (ctx_kv_fused_ok(u, Tp)) {  // k_proj | v_proj rows are adjacent in the blob: one GEMM, the V half stored transposed (GemmArgs::Vt)
+  if (ctx_kv_fused_ok(ctx, u, Tp)) {  // k_proj | v_proj rows are adjacent in the blob: one GEMM, the V half stored transposed (GemmArgs::Vt)
     GemmArgs g;
     g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
     g.M = B * Tp; g.N = 2 * CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
@@ -556,8 +552,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
   TSD_TRY(launch_small_linear(ctx, time, B, 1280, 1280, u.tproj.w, u.tproj.Kpad, u.tproj.b, u.tproj.N, 1, tvec,
                               u.tproj.N));
   const int tld = u.tproj.N;
-  static const int im2col_on = getenv("TSD_CONV_IN_IM2COL") ? atoi(getenv("TSD_CONV_IN_IM2COL")) : 1;
-  const bool in_im2col = im2col_on && u.conv_in_im2col && !u.conv.empty() && u.conv[0].I == 4 && SD15_STEPS[0].l.kind == L_CONV &&
+  const bool in_im2col = ctx->opt.conv_in_im2col && u.conv_in_im2col && !u.conv.empty() && u.conv[0].I == 4 && SD15_STEPS[0].l.kind == L_CONV &&
                          SD15_STEPS[0].l.d == 1;  // as in g_unet_forward: the 4-channel input convolution as one im2col K tile
   Act x0 = act_alloc(ctx, B, L, L, 64); CHECK_ALLOC(x0.p);
   if (in_im2col) TSD_TRY(launch_chw_f32_to_im2col3x3_f16(ctx, latents_chw, B, 4, L, L, x0.p));
@@ -566,7 +561,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
   const int CK = u.kproj_all.N;
   half_t* kc_all = arena_alloc<half_t>(ctx, (int64_t)B * Tp * CK); CHECK_ALLOC(kc_all);
   half_t* vtc_all = arena_alloc<half_t>(ctx, (int64_t)B * CK * Tp); CHECK_ALLOC(vtc_all);
-  if (ctx_kv_fused_ok(u, Tp)) {  // k_proj | v_proj rows are adjacent in the blob: one GEMM, the V half stored transposed (GemmArgs::Vt)
+  if (ctx_kv_fused_ok(ctx, u, Tp)) {  // k_proj | v_proj rows are adjacent in the blob: one GEMM, the V half stored transposed (GemmArgs::Vt)
     GemmArgs g;
     g.A0 = ctx16; g.lda0 = u.kproj_all.Kpad; g.Wt = u.kproj_all.w; g.ldw = u.kproj_all.Kpad;
     g.M = B * Tp; g.N = 2 * CK; g.K = u.kproj_all.Kpad; g.C = kc_all; g.ldc = CK;
@@ -648,8 +643,7 @@ static int g_unet_full_forward(tsd_model* m, const float* latents_chw, const hal
 // The first convolution of either VAE half reads 3 / 4 channels padded to 64: as in the UNet (g_unet_forward) the boundary gathers im2col
 // rows and the layer runs as one 64-deep K tile
 static bool vae_in_im2col(const tsd_model* m, const LayerDef* layers) {
-  static const int on = getenv("TSD_CONV_IN_IM2COL") ? atoi(getenv("TSD_CONV_IN_IM2COL")) : 1;
-  return on && m->vae.conv_in_im2col && layers[0].kind == L_CONV && layers[0].c == 3 && !m->vae.conv.empty() && m->vae.conv[0].I <= 7;
+  return m->ctx->opt.conv_in_im2col && m->vae.conv_in_im2col && layers[0].kind == L_CONV && layers[0].c == 3 && !m->vae.conv.empty() && m->vae.conv[0].I <= 7;
 }
 static int run_vae(tsd_model* m, const LayerDef* layers, int n_layers, Act cur, bool final_f32, float* out_nhwc_f32,
                    int* out_side, int* out_ld) {

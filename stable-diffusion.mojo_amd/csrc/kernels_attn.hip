@@ -32,6 +32,8 @@
 #include <vector>
 #include <algorithm>
 #include <type_traits>
+#include <atomic>
+
 #include "common.h"
 #include "lds_dma.h"
 
@@ -56,6 +58,7 @@ struct AttnK {
   int diag;            // self-attention (Sq == Sk): the optimistic reference also covers each query's own 32-key block
   int xcd_map;         // 1: (head, query tile) remapped so that every XCD (dispatch id % 8) owns whole heads - its L2 then pulls a head's
                        // K / V^T once instead of every XCD pulling every head's (needs B*H % 8 == 0)
+  int* exact_ctr;      // the context's count of workgroups that had to run the exact pass (tsd_debug_attn_exact_passes)
 };
 
 __device__ __forceinline__ void glds16a(const void* g, void* l) {
@@ -66,7 +69,6 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 #ifdef TSD_ATTN_TS
 __device__ unsigned long long g_attn_ts[4 * 65536];  // per block: memtime start/end, memrealtime start/end
 #endif
-__device__ unsigned g_attn_exact_wg;  // workgroups that had to run the exact pass (tsd_debug_attn_exact_passes)
 // Largest score (log2 units, relative to the running reference) a tile may reach before the reference is moved.
 // P = exp2(s - ref) is then at most 2^12 - far inside fp16 (65504) and harmless for the fp32 O / row-sum accumulators.
 #define TSD_ATTN_LAZY 12.0f
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
       }
     }
     if (__syncthreads_or(bad)) {
-      if (tid == 0) atomicAdd(&g_attn_exact_wg, 1u);
+      if (tid == 0) atomicAdd(p.exact_ctr, 1);
       run(std::true_type{});
 #pragma unroll
       for (int qb = 0; qb < QB; qb++) l_tot[qb] = row_sum(qb);
@@ -487,17 +489,18 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
 }
 
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
-static int g_attn_qb = 2;     // d = 40: 32-query blocks per wave (TSD_ATTN_QB=1 selects the 128-query workgroup)
-static int g_attn_qb_force = 0;  // tsd_debug_set_attn_qb: 0 = by shape, 1 / 2 = that many query blocks per wave whenever d = 40
-static int g_attn_diag = 1;  // tsd_debug_set_attn_diag: 0 = optimistic reference from key tile 0 only (the round-2 behaviour)
-extern "C" int tsd_debug_set_attn_diag(int on) {
-  const int prev = g_attn_diag;
-  if (on == 0 || on == 1) g_attn_diag = on;
+// per-context switches (TsdOptions): attn_diag 0 = optimistic reference from key tile 0 only (the round-2 behaviour);
+// attn_qb_force 0 = 32- / 64-query waves chosen by the layer shape, 1 / 2 = that many query blocks per wave whenever d = 40
+extern "C" int tsd_debug_set_attn_diag(tsd_ctx* ctx, int on) {
+  if (!ctx) return TSD_E_ARG;
+  const int prev = ctx->opt.attn_diag;
+  if (on == 0 || on == 1) { ctx->opt.attn_diag = on; ctx->opt.gen++; }
   return prev;
 }
-extern "C" int tsd_debug_set_attn_qb(int mode) {
-  const int prev = g_attn_qb_force;
-  if (mode >= 0 && mode <= 2) g_attn_qb_force = mode;
+extern "C" int tsd_debug_set_attn_qb(tsd_ctx* ctx, int mode) {
+  if (!ctx) return TSD_E_ARG;
+  const int prev = ctx->opt.attn_qb_force;
+  if (mode >= 0 && mode <= 2) { ctx->opt.attn_qb_force = mode; ctx->opt.gen++; }
   return prev;
 }
 template <int D, int QB>
@@ -505,10 +508,10 @@ static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
   constexpr int LDS = 2 * (64 * KPITCH * 16 + DBLK * 32 * 128);
   auto fn = flash_attn_kernel<D, QB>;
-  static unsigned long long attr = 0;  // one bit per device
-  if (!((attr >> (ctx->device & 63)) & 1)) {
+  static std::atomic<unsigned long long> attr{0};  // one bit per device
+  if (!((attr.load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr |= 1ull << (ctx->device & 63);
+    attr.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(fn, dim3(ceil_div(Sq, 128 * QB), B * H), dim3(256), LDS, ctx->stream, k);
   HIP_TRY(hipGetLastError());
@@ -520,10 +523,6 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4) TSD_FAIL(TSD_E_SHAPE, "flash attention: misaligned pitches");
   if (a.Sq <= 0 || a.Sk <= 0) TSD_FAIL(TSD_E_SHAPE, "flash attention: empty sequence");
   if (!ctx->launch()) return TSD_OK;
-  {
-    static bool env_read = false;
-    if (!env_read) { const char* e = getenv("TSD_ATTN_QB"); if (e && (e[0] == '1' || e[0] == '2')) g_attn_qb = e[0] - '0'; env_read = true; }
-  }
   ProfScope prof(ctx, KC_ATTN, a.Sq, a.Sk, a.d, a.B * a.H);
   AttnK k;
   k.Q = a.Q; k.K = a.K; k.Vt = a.Vt; k.O = a.O; k.zeros = ctx->zeros; k.ones = ctx->zeros + 1024;
@@ -531,13 +530,13 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   k.ldq = a.ldq; k.ldk = a.ldk; k.ldvt = a.ldvt; k.ldo = a.ldo;
   k.H = a.H; k.Sq = a.Sq; k.Sk = a.Sk; k.Skv = std::min(round_up(a.Sk, 8), a.ldvt);
   k.c = a.scale * 1.4426950408889634f;
-  k.diag = (g_attn_diag && a.Sq == a.Sk) ? 1 : 0;
+  k.exact_ctr = ctx->status + 2;
+  k.diag = (ctx->opt.attn_diag && a.Sq == a.Sk) ? 1 : 0;
   // long key loops only (the K / V^T stream of a head is what the remap saves); results do not depend on the block order.
   // Measured (profiles/r03_attn_xcd_ab.txt): FETCH_SIZE of the 4096 x 4096 d = 40 call 366 -> 144 MB, of the 1024 x 1024 d = 80 call
   // 103 -> 33 MB (-0.9 GB of a step's 10.9 GB) and 201.1 against 201.5 steps/s - the kernel is not bound by that stream (all of it
   // Infinity-Cache hits) and eight whole heads per XCD (5.2 MB of K / V^T) no longer fit its 4 MB L2.  OFF by default (TSD_ATTN_XCD=1).
-  static const int xcd_on = getenv("TSD_ATTN_XCD") ? atoi(getenv("TSD_ATTN_XCD")) : 0;
-  k.xcd_map = (xcd_on && (a.B * a.H) % 8 == 0 && a.Sk >= 512) ? 1 : 0;
+  k.xcd_map = (ctx->opt.attn_xcd && (a.B * a.H) % 8 == 0 && a.Sk >= 512) ? 1 : 0;
   switch (a.d) {
     case 40:
       // 64 queries per wave when the key loop is long enough to matter: 4096 x 4096 at B*H = 64 runs 253 -> 243 us (half the
@@ -545,7 +544,7 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
       // The choice keys on the layer (Sq, Sk, H), never on the batch: the two variants are bitwise equal only while no
       // workgroup repeats exactly (the repeat is decided per 128- / 256-query workgroup and moves the reference per 32 / 64
       // rows), so a sample computed alone must run the same variant as its row of a batch (bitwise batch invariance).
-      if (g_attn_qb_force ? g_attn_qb_force == 2 : (g_attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.H >= 64))
+      if (ctx->opt.attn_qb_force ? ctx->opt.attn_qb_force == 2 : (ctx->opt.attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.H >= 64))
         return launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq);
       return launch_fa<40, 1>(ctx, k, a.B, a.H, a.Sq);
     case 80: return launch_fa<80, 1>(ctx, k, a.B, a.H, a.Sq);
@@ -553,14 +552,14 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
   }
 }
 
-// Workgroups of flash_attn_kernel that ran the exact pass since the last reset (device-wide; synchronises the stream).
+// Workgroups of flash_attn_kernel that ran the exact pass on this context since the last reset (synchronises the stream).
 extern "C" int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset) {
-  if (!ctx) return -1;
+  if (!ctx || !ctx->status) return -1;
   if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
-  unsigned v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_exact_wg), sizeof(v)) != hipSuccess) return -1;
-  if (reset) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_exact_wg), &z, sizeof(z)) != hipSuccess) return -1; }
-  return (int)std::min(v, 0x7fffffffu);
+  int v = 0;
+  if (hipMemcpy(&v, ctx->status + 2, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset) { const int z = 0; if (hipMemcpy(ctx->status + 2, &z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) return -1; }
+  return v < 0 ? 0x7fffffff : v;
 }
 
 // Debug/bench entry: time `iters` launches of the fused attention core on synthetic device data.

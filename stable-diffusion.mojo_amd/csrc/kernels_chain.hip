@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -843,6 +844,9 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     }
     // ---- G2(8)'s last tile with unit 3 of chunk 9, publish, then G2(9) ----
     gstep(I2{}, I0{}, I0{}, I0{}, I3{}, I0{});
+    // that step had no tile barrier (CK = 0): G2(8)'s last reads of the activation tile by the OTHER column wave must have retired
+    // before this wave overwrites its rows with chunk 9 (inside the loop the publish sits two barriers behind the last read)
+    lds_barrier();
     write_act();
     gstep(I0{}, I2{}, I0{}, I0{}, IM1{}, I0{});
     gstep(I2{}, I2{}, I1{}, I1{}, IM1{}, I0{});
@@ -950,17 +954,16 @@ extern "C" int tsd_debug_chain_ts(unsigned long long* out, int n, int kind) {
 // ---- host side ----------------------------------------------------------------------------------------------------
 size_t attn_tail_stream_bytes() { return (size_t)STREAM_BYTES; }
 
-static int g_chain_on = -1;  // -1: read TSD_CHAIN on first use
-// debug / A-B switch: 1 = fused head / tail kernels at the 64x64 level (default), 0 = the op-by-op graph; returns the old value
-extern "C" int tsd_debug_set_fused_attention(int on) {
-  const int old = g_chain_on < 0 ? (getenv("TSD_CHAIN") ? atoi(getenv("TSD_CHAIN")) : 1) : g_chain_on;
-  g_chain_on = on ? 1 : 0;
+// debug / A-B switch of ONE context: 1 = fused head / tail kernels at the 64x64 level (default), 0 = the op-by-op graph; returns the old value
+extern "C" int tsd_debug_set_fused_attention(tsd_ctx* ctx, int on) {
+  if (!ctx) return TSD_E_ARG;
+  const int old = ctx->opt.chain;
+  ctx->opt.chain = on ? 1 : 0;
+  ctx->opt.gen++;
   return old;
 }
-bool attn_tail_supported(int C_, int d, int heads, int T, int64_t M, int S) {
-  if (g_chain_on < 0) g_chain_on = getenv("TSD_CHAIN") ? atoi(getenv("TSD_CHAIN")) : 1;
-  const int on = g_chain_on;
-  return on && C_ == 320 && d == 40 && heads == 8 && T >= 1 && T <= 80 && S % 64 == 0 && M % 64 == 0 && M < (1 << 24);
+bool attn_tail_supported(const tsd_ctx* ctx, int C_, int d, int heads, int T, int64_t M, int S) {
+  return ctx->opt.chain && C_ == 320 && d == 40 && heads == 8 && T >= 1 && T <= 80 && S % 64 == 0 && M % 64 == 0 && M < (1 << 24);
 }
 
 // pack the six weight matrices of one attention block (fp16, reference-packed [N][K] with the GEGLU rows interleaved)
@@ -977,7 +980,7 @@ int launch_attn_tail_pack(tsd_ctx* ctx, const half_t* Wso, int ld_so, const half
 }
 
 int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
-  if (!attn_tail_supported(a.C, a.d, a.heads, a.T, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention tail: unsupported shape");
+  if (!attn_tail_supported(ctx, a.C, a.d, a.heads, a.T, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention tail: unsupported shape");
   if (!a.wstream) TSD_FAIL(TSD_E_ARG, "attention tail: weights were not packed");
   if (a.ld_ao % 8 || a.ld_tok % 8 || a.ld_x % 8 || a.ld_out % 8 || a.ldk % 8 || a.ldvt % 8 || a.ld_ao < 320 || a.ld_tok < 320 ||
       a.ld_x < 320 || a.ld_out < 320 || a.ldk < 320 || a.ldvt < ((a.T + 7) & ~7))
@@ -998,10 +1001,10 @@ int launch_attn_tail(tsd_ctx* ctx, const AttnTailArgs& a) {
   k.qscale = a.scale * 1.4426950408889634f; k.eps = a.eps;
   k.gn_part = a.gn_part; k.gn_nslab = a.gn_nslab;
   k.gn_stats = nullptr; k.b_in = nullptr; k.tok_out = nullptr; k.qk = nullptr; k.ld_qk = 0; k.vt = nullptr; k.ld_vt = 0; k.s_vt = 0;
-  static unsigned long long attr = 0;  // one bit per device
-  if (!((attr >> (ctx->device & 63)) & 1)) {
+  static std::atomic<unsigned long long> attr{0};  // one bit per device (setting the attribute twice is harmless; the mask is only a shortcut)
+  if (!((attr.load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)attn_chain_kernel<KIND_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr |= 1ull << (ctx->device & 63);
+    attr.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(attn_chain_kernel<KIND_TAIL>, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
   HIP_TRY(hipGetLastError());
@@ -1021,7 +1024,7 @@ int launch_attn_head_pack(tsd_ctx* ctx, const half_t* Wc, int ld_c, const half_t
 }
 
 int launch_attn_head(tsd_ctx* ctx, const AttnHeadArgs& a) {
-  if (!attn_tail_supported(320, 40, 8, 1, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention head: unsupported shape");
+  if (!attn_tail_supported(ctx, 320, 40, 8, 1, a.M, a.S)) TSD_FAIL(TSD_E_SHAPE, "attention head: unsupported shape");
   if (!a.wstream || !a.gn_stats) TSD_FAIL(TSD_E_ARG, "attention head: weights were not packed / statistics missing");
   if (a.ld_x % 8 || a.ld_tok % 8 || a.ld_qk % 8 || a.ld_vt % 8 || a.ld_x < 320 || a.ld_tok < 320 || a.ld_qk < 640 || a.ld_vt < a.S)
     TSD_FAIL(TSD_E_SHAPE, "attention head: misaligned or too narrow pitches");
@@ -1033,10 +1036,10 @@ int launch_attn_head(tsd_ctx* ctx, const AttnHeadArgs& a) {
   k.vt = a.vt; k.ld_vt = a.ld_vt; k.s_vt = a.s_vt;
   k.wstream = a.wstream; k.b_in = a.b_in; k.gn_stats = a.gn_stats;
   k.M = (int)a.M; k.S = a.S; k.eps = a.eps; k.T = 1;
-  static unsigned long long attr = 0;  // one bit per device
-  if (!((attr >> (ctx->device & 63)) & 1)) {
+  static std::atomic<unsigned long long> attr{0};  // one bit per device
+  if (!((attr.load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)attn_chain_kernel<KIND_HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr |= 1ull << (ctx->device & 63);
+    attr.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(attn_chain_kernel<KIND_HEAD>, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, ctx->stream, k);
   HIP_TRY(hipGetLastError());

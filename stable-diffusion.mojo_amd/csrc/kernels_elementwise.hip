@@ -1,6 +1,8 @@
 // kernels_elementwise.hip - HBM-bound helpers: boundary layout conversion (reference CHW fp32 <->
 // device NHWC fp16), op-level fp32 elementwise ops, row softmax, time embedding, the tiny
 // M<=16 linears of the time path, weight packing, counter-RNG init and the DDPM update.
+#include <atomic>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -108,23 +110,37 @@ int launch_pack_tile_major(tsd_ctx* ctx, const half_t* w, int N, int K, half_t* 
   return TSD_OK;
 }
 
+// ---- non-finite accounting at the device -> caller exits ------------------------------------------------------------------
+// The reference computes in fp32 (helpers/utils.mojo:12-15) and cannot overflow at the path's magnitudes; this path stores
+// activations as fp16 (|x| <= 65504).  An overflow turns into inf / NaN that the following norms and GEMMs spread, so it reaches
+// the tensors that LEAVE the device: every kernel that produces a caller-visible tensor counts the non-finite values it writes in
+// the context's status word, and the synchronisation points of the ABI turn a non-zero count into TSD_E_NONFINITE (runtime.cpp).
+__device__ __forceinline__ bool nonfinite_f(float v) { return !(fabsf(v) <= 3.4028234e38f); }  // inf or NaN
+__device__ __forceinline__ void nonfinite_report(int* counter, int nbad) {
+  if (nbad) atomicAdd(counter, nbad);  // rare path
+}
+
 template <class T>
 __global__ void k_nhwc_to_chw(const T* __restrict__ src, int C, int HW, int ld, float* __restrict__ dst,
-                              int64_t total) {
+                              int64_t total, int* __restrict__ nonfinite) {
+  int nbad = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = i % HW;
     const int64_t bc = i / HW;
     const int c = (int)(bc % C);
     const int64_t b = bc / C;
-    dst[i] = (float)src[(b * HW + pix) * ld + c];
+    const float v = (float)src[(b * HW + pix) * ld + c];
+    nbad += nonfinite_f(v);
+    dst[i] = v;
   }
+  nonfinite_report(nonfinite, nbad);
 }
 int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst) {
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = (int64_t)B * C * H * W;
   ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_nhwc_to_chw<half_t>, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, ld, dst,
-                     total);
+                     total, ctx->status);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -133,7 +149,7 @@ int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int
   const int64_t total = (int64_t)B * C * H * W;
   ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_nhwc_to_chw<float>, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, C, H * W, ld, dst,
-                     total);
+                     total, ctx->status);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -158,17 +174,21 @@ int launch_f32_to_f16_rows(tsd_ctx* ctx, const float* src, int64_t rows, int col
   return TSD_OK;
 }
 __global__ void k_f16_to_f32_rows(const half_t* __restrict__ src, int cols, int ld, float* __restrict__ dst,
-                                  int64_t total) {
+                                  int64_t total, int* __restrict__ nonfinite) {
+  int nbad = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cols;
     const int c = (int)(i - r * cols);
-    dst[i] = (float)src[r * ld + c];
+    const float v = (float)src[r * ld + c];
+    nbad += nonfinite_f(v);
+    dst[i] = v;
   }
+  nonfinite_report(nonfinite, nbad);
 }
 int launch_f16_to_f32_rows(tsd_ctx* ctx, const half_t* src, int64_t rows, int cols, int ld_src, float* dst) {
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = rows * cols;
-  hipLaunchKernelGGL(k_f16_to_f32_rows, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, cols, ld_src, dst, total);
+  hipLaunchKernelGGL(k_f16_to_f32_rows, GRID1D(total, 256), dim3(256), 0, ctx->stream, src, cols, ld_src, dst, total, ctx->status);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -178,19 +198,21 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 __device__ __forceinline__ float gelu_f(float x) {                                   // helpers/utils.mojo:1914
   return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
-__global__ void k_unary(int op, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+__global__ void k_unary(int op, const float* __restrict__ x, int64_t n, float* __restrict__ y, int* __restrict__ nonfinite) {
+  int nbad = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float v = x[i];
     float r;
     if (op == 0) r = v / (1.f + expf(-v));
     else if (op == 1) r = gelu_f(v);
-    else r = fminf(fmaxf((v + 1.f) * 127.5f, 0.f), 255.f);  // pipeline.mojo:127
+    else { r = fminf(fmaxf((v + 1.f) * 127.5f, 0.f), 255.f); nbad += nonfinite_f(v); }  // pipeline.mojo:127 (the clamp would swallow a NaN)
     y[i] = r;
   }
+  nonfinite_report(nonfinite, nbad);
 }
 int launch_unary_f32(tsd_ctx* ctx, int op, const float* x, int64_t n, float* y) {
   if (!ctx->launch()) return TSD_OK;
-  hipLaunchKernelGGL(k_unary, GRID1D(n, 256), dim3(256), 0, ctx->stream, op, x, n, y);
+  hipLaunchKernelGGL(k_unary, GRID1D(n, 256), dim3(256), 0, ctx->stream, op, x, n, y, ctx->status);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -507,12 +529,12 @@ int launch_small_linear(tsd_ctx* ctx, const float* x, int B, int K, int ldx, con
   ProfScope prof(ctx, KC_SMALL_LINEAR, B, N, K, 1);
   const size_t lds = (size_t)B * K * sizeof(float);
   if (lds > 160 * 1024) TSD_FAIL(TSD_E_SHAPE, "small_linear: B*K too large for LDS");
-  static unsigned long long attr_set[5] = {0, 0, 0, 0, 0};  // per DEVICE: the attribute is stored per device (one bit each)
+  static std::atomic<unsigned long long> attr_set[5];  // per DEVICE: the attribute is stored per device (one bit each); zero-initialised
   const int slot = B <= 1 ? 0 : B <= 2 ? 1 : B <= 4 ? 2 : B <= 8 ? 3 : 4;
   auto launch = [&](auto fn) -> int {
-    if (!((attr_set[slot] >> (ctx->device & 63)) & 1)) {
+    if (!((attr_set[slot].load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {
       HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set[slot] |= 1ull << (ctx->device & 63);
+      attr_set[slot].fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(fn, dim3(ceil_div(N, 16)), dim3(256), lds, ctx->stream, x, B, K, ldx, w, ldw, bias, N, silu_in, y, ldy);
     return TSD_OK;
@@ -644,7 +666,8 @@ int launch_pack_bias(tsd_ctx* ctx, const float* src, int N, float* dst, int Npad
 // eps_hw > 0: eps / eps_u are the UNet output convolution's own layout [B][eps_hw][4] (x and noise stay CHW [B][4][eps_hw])
 __global__ void k_ddpm_step(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ eps_u,
                             float cfg_scale, const float* __restrict__ noise, int64_t n, float sa, float sb,
-                            float c_x0, float c_xt, float sigma, int eps_hw) {
+                            float c_x0, float c_xt, float sigma, int eps_hw, int* __restrict__ nonfinite) {
+  int nbad = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t ie = i;
     if (eps_hw > 0) {
@@ -660,15 +683,17 @@ __global__ void k_ddpm_step(float* __restrict__ x, const float* __restrict__ eps
     const float x0 = (xv - e * sb) / sa;
     float o = x0 * c_x0 + xv * c_xt;
     if (noise) o += noise[i] * sigma;
+    nbad += nonfinite_f(o);  // a non-finite UNet output (fp16 overflow upstream) lands here every step
     x[i] = o;
   }
+  nonfinite_report(nonfinite, nbad);
 }
 int launch_ddpm_step(tsd_ctx* ctx, float* latents, const float* eps, const float* eps_uncond, float cfg_scale,
                      const float* noise, int64_t n, float sa, float sb, float c_x0, float c_xt, float sigma, int eps_hw) {
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_ELEMENTWISE);
   hipLaunchKernelGGL(k_ddpm_step, GRID1D(n, 256), dim3(256), 0, ctx->stream, latents, eps, eps_uncond, cfg_scale,
-                     noise, n, sa, sb, c_x0, c_xt, sigma, eps_hw);
+                     noise, n, sa, sb, c_x0, c_xt, sigma, eps_hw, ctx->status);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }
@@ -684,24 +709,27 @@ int launch_add_noise(tsd_ctx* ctx, float* latents, const float* noise, int64_t n
 }
 // `Encoder.metrics_evals` vae.mojo:118-129: moments NHWC fp32 [B][HW][ld] (mean ch 0..3, logvar 4..7)
 __global__ void k_encoder_sample(const float* __restrict__ mom, int HW, int ld, const float* __restrict__ noise,
-                                 float* __restrict__ out, int64_t total) {
+                                 float* __restrict__ out, int64_t total, int* __restrict__ nonfinite) {
+  int nbad = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = i % HW;
     const int c = (int)((i / HW) % 4);
     const int64_t b = i / ((int64_t)4 * HW);
     const float* mp = mom + (b * HW + pix) * ld;
     const float mean = mp[c];
+    nbad += nonfinite_f(mean) + nonfinite_f(mp[4 + c]);  // the clamp below would swallow a NaN log-variance
     const float lv = fminf(fmaxf(mp[4 + c], -30.f), 20.f);
     const float sd = sqrtf(expf(lv));
     out[i] = (mean + noise[i] * sd) * 0.18215f;
   }
+  nonfinite_report(nonfinite, nbad);
 }
 int launch_encoder_sample(tsd_ctx* ctx, const float* moments_nhwc, int B, int HW, int ld, const float* noise_chw,
                           float* latents_chw) {
   if (!ctx->launch()) return TSD_OK;
   const int64_t total = (int64_t)B * 4 * HW;
   hipLaunchKernelGGL(k_encoder_sample, GRID1D(total, 256), dim3(256), 0, ctx->stream, moments_nhwc, HW, ld, noise_chw,
-                     latents_chw, total);
+                     latents_chw, total, ctx->status);
   HIP_TRY(hipGetLastError());
   return TSD_OK;
 }

@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -1056,11 +1057,11 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   constexpr bool HX = CV == 1;
   constexpr int LDS = HX ? NS * BN * 128 + 2 * (BM / 8 + 1) * 1024 : NS * (BM + BN) * 128;
   auto fn = gemm_kernel<WGM, WGN, FM, FN, CONV, NS, PP, CV, LW>;
-  static unsigned long long attr_set = 0;  // per DEVICE: the attribute is stored per device (one bit each)
-  if (!((attr_set >> (ctx->device & 63)) & 1)) {
+  static std::atomic<unsigned long long> attr_set{0};  // per DEVICE: the attribute is stored per device (one bit each; setting it twice is harmless)
+  if (!((attr_set.load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set |= 1ull << (ctx->device & 63);
-    if (getenv("TSD_DEBUG_OCC")) {
+    attr_set.fetch_or(1ull << (ctx->device & 63), std::memory_order_relaxed);
+    if (ctx->opt.debug_occ) {
       int nb = -1;
       hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, (WGM * WGN + LW) * 64, LDS);
       fprintf(stderr, "[occ] gemm<%d,%d,%d,%d,%d,%d,lw%d> LDS=%d blocks/CU=%d (%s)\n", WGM, WGN, FM, FN, (int)CONV, NS, LW, LDS, nb,
@@ -1074,7 +1075,7 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
   kk.tiles_n = ceil_div(k.N, BN);
   const int tiles_m = ceil_div(k.M, BM);
   {  // XCD grid: minimise W_bytes * xm + A_bytes * xn over the factorizations of 8 that divide the tile grid
-    static const int force = getenv("TSD_GEMM_XCDN") ? atoi(getenv("TSD_GEMM_XCDN")) : 0;
+    const int force = ctx->opt.xcdn;
     const double wb = 2.0 * k.N * k.K;
     const double ab = CONV ? 2.0 * (k.M / (k.Ho * k.Wo)) * k.Hs * k.Ws * k.Cin : 2.0 * (double)k.M * k.K;
     int best = 1;
@@ -1112,7 +1113,6 @@ static int launch_cfg(tsd_ctx* ctx, const GemmK& k, int batch) {
 //  12  256x160   2      104 KiB   8 waves
 //  13  256x128   3      144 KiB   8 waves
 constexpr int N_GEMM_CFG = 56;
-static int g_force_cfg = -1;  // debug/bench override (tsd_debug_gemm_bench)
 
 // SKV = 2 for a conv3x3 with a fused 1x1 skip source (GemmK::Cin1 > 0), else 0: the plain kernels carry none of its scalar state
 template <bool CONV, int SKV = 0>
@@ -1172,12 +1172,8 @@ static int launch_by_id(tsd_ctx* ctx, const GemmK& k, int batch, int id) {
 // configuration runs depends on M - a sample computed alone would no longer equal its row of a batch bit for bit.  Measured
 // with it on (TSD_CONV_HALO=1: the 128x128-tile convs, 2: the 128x160 ones too): decoder 26.1 -> 25.7 ms, encoder 13.95 ->
 // 13.70 ms, UNet step unchanged.  tests/test_gpu_ops.py keeps the path correct against the plain configurations.
-static int hx_mode() {
-  static const int on = getenv("TSD_CONV_HALO") ? atoi(getenv("TSD_CONV_HALO")) : 0;
-  return on;
-}
 static bool hx_shape_ok(const GemmK& k);
-static bool hx_eligible(const GemmK& k) { return hx_mode() > 0 && hx_shape_ok(k); }
+static bool hx_eligible(const TsdOptions& o, const GemmK& k) { return o.conv_halo > 0 && hx_shape_ok(k); }
 static bool hx_shape_ok(const GemmK& k) {
   return k.stride == 1 && !k.ups && k.pad == 1 && k.splitk <= 1 && !k.Cin1 && k.Hs == k.Ho && k.Ws == k.Wo && k.Cin % 64 == 0 &&
          (k.Wo == 64 || k.Wo % 128 == 0) && ((long long)k.Ho * k.Wo) % 128 == 0 && k.M % 128 == 0 && k.Ho < 2040 && k.Wo < 2040;
@@ -1194,9 +1190,9 @@ __global__ void k_probe_xcc(int* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 0xf);
 }
 static bool xcd_round_robin() {
-  static int ok = -1;
-  if (ok >= 0) return ok != 0;
-  ok = 0;
+  static std::atomic<int> cached{-1};  // a probe result: every thread computes the same value
+  if (cached.load(std::memory_order_relaxed) >= 0) return cached.load(std::memory_order_relaxed) != 0;
+  int ok = 0;
   const int nb = 1024;
   int* d = nullptr;
   if (hipMalloc((void**)&d, nb * sizeof(int)) != hipSuccess) return false;
@@ -1208,29 +1204,27 @@ static bool xcd_round_robin() {
     for (int i = 0; i < 8; i++) for (int j = 0; j < i; j++) if (h[i] == h[j]) ok = 0;
   }
   hipFree(d);
-  if (!ok && getenv("TSD_DEBUG_OCC")) fprintf(stderr, "[gemm] workgroup -> XCD mapping is not round-robin: split-K disabled\n");
+  cached.store(ok, std::memory_order_relaxed);
   return ok != 0;
 }
 extern "C" int tsd_debug_xcd_round_robin(void) { return xcd_round_robin() ? 1 : 0; }
 
-static thread_local int g_sk_big_graph = 0;  // slices for K >= 8192 at the 16x16 level asked for by the running graph (0: default)
-int gemm_set_splitk_big(int ways) { const int prev = g_sk_big_graph; g_sk_big_graph = ways; return prev; }
+// slices for K >= 8192 at the 16x16 level asked for by the graph being enqueued on this context (0: default)
+int gemm_set_splitk_big(tsd_ctx* ctx, int ways) { const int prev = ctx->opt.sk_big_graph; ctx->opt.sk_big_graph = ways; return prev; }
 // Split-K plan: number of K slices (1 = none) and the tile configuration the split launch runs with.
-static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
-  static const int on = getenv("TSD_GEMM_SPLITK") ? atoi(getenv("TSD_GEMM_SPLITK")) : 1;
+static int splitk_plan(const TsdOptions& o, int M, int N, int K, int batch, int rps, int* cfg) {
+  const int on = o.splitk;
   // The decision must not depend on the batch size (bitwise batch invariance: a split changes the fp32 summation
   // tree), so it keys on the layer: rows per sample, N and K.
   //  * rps <= 256 (the 16x16 level of a 64x64 latent): 2 slices of 128-row tiles once K >= 4096;
   //  * rps <= 64 (an 8x8 level: the full-size UNet's deepest at a 64x64 latent, the 23-layer graph's at 32x32): M is
   //    a few hundred rows, so 64-row tiles and up to 8 slices - 32 tiles x 8 fill the chip where 16 tiles x 2 left
   //    7/8 of it idle.
-  static const int min_k = getenv("TSD_GEMM_SPLITK_MINK") ? atoi(getenv("TSD_GEMM_SPLITK_MINK")) : 4096;
-  static const int max_tiles = getenv("TSD_GEMM_SPLITK_TILES") ? atoi(getenv("TSD_GEMM_SPLITK_TILES")) : 256;
-  static const int small_ways = getenv("TSD_GEMM_SPLITK_SMALL") ? atoi(getenv("TSD_GEMM_SPLITK_SMALL")) : 8;
+  const int min_k = o.splitk_mink, max_tiles = o.splitk_tiles, small_ways = o.splitk_small;
   // Round 3 (late): two more layer classes that left half the chip idle at batch 8 -
   //  * rps <= 256 with at most 4 tile columns (the 32x32 -> 16x16 downsampling conv, N = 640, K = 5760: 64 tiles): 4 slices;
   //  * rps <= 1024 with N * rps <= 320 * 1024 (the 64x64 -> 32x32 downsampling conv, N = 320, K = 2880: 128 tiles): 2 slices.
-  static const int wide = getenv("TSD_GEMM_SPLITK_WIDE") ? atoi(getenv("TSD_GEMM_SPLITK_WIDE")) : 1;
+  const int wide = o.splitk_wide;
   const bool mid = wide && rps > 256 && rps <= 1024 && (long long)N * rps <= 320LL * 1024 && K >= 2880;
   if (!on || batch != 1 || N <= 16 || rps <= 0 || (rps > 256 && !mid)) return 1;
   const bool n160 = (N % 160 == 0);
@@ -1240,17 +1234,17 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
     ways = K >= 8192 ? 8 : (K >= 2048 ? 4 : (K >= 1024 ? 2 : 1));
     if (ways > small_ways) ways = small_ways;
     BM = 64;
-    static const int deep = getenv("TSD_GEMM_SPLITK_RING4") ? atoi(getenv("TSD_GEMM_SPLITK_RING4")) : 0;
+    const int deep = o.splitk_ring4;
     if (cfg) *cfg = deep ? (n160 ? 6 : 9) : (n160 ? 7 : 10);
   } else {
-    static const int big_env = getenv("TSD_GEMM_SPLITK_BIG") ? atoi(getenv("TSD_GEMM_SPLITK_BIG")) : 0;
+    const int big_env = o.splitk_big;
     // 2 slices for the 23-layer UNet at batch 8; the full-size UNet's graph asks for 4 (gemm_set_splitk_big: +4.3 % at its batch of 4,
     // -0.8 % on the headline).  A per-GRAPH choice, so every batch size of a model sums in the same tree.
-    const int big_ways = big_env ? big_env : (g_sk_big_graph ? g_sk_big_graph : 2);
+    const int big_ways = big_env ? big_env : (o.sk_big_graph ? o.sk_big_graph : 2);
     ways = K >= 8192 ? big_ways : (K >= min_k ? 2 : 1);
     if (wide && ways == 2 && ceil_div(N, BN) <= 4) ways = 4;
     if (mid) ways = 2;
-    static const int sk128 = getenv("TSD_GEMM_SK_CFG") ? atoi(getenv("TSD_GEMM_SK_CFG")) : 5;  // 45: the same tile with loader waves
+    const int sk128 = o.sk_cfg;  // 45: the same tile with loader waves
     if (cfg) *cfg = n160 ? sk128 : 8;
   }
   // Eligibility looks at N only (8 | N-tiles keeps a tile's slices on one XCD for any M): a condition on the tile
@@ -1262,10 +1256,10 @@ static int splitk_plan(int M, int N, int K, int batch, int rps, int* cfg) {
   if (ways == 1 || !xcd_ok || tiles > 2 * max_tiles || (ways - 1) * tiles > 4095) return 1;
   return ways;
 }
-static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
+static int choose_cfg(const TsdOptions& o, int M, int N, int K, int batch, bool conv, int rps = 0) {
   {  // tuning aid: TSD_GEMM_CFG_OVERRIDE="M,N,K:cfg[;M,N,K:cfg...]" forces a tile configuration for exact shapes inside a real step
-    static const char* ov = getenv("TSD_GEMM_CFG_OVERRIDE");
-    if (ov) {
+    const char* ov = o.cfg_override;
+    if (ov[0]) {
       for (const char* q = ov; q && *q;) {
         int m = 0, n = 0, k = 0, c = 0;
         if (sscanf(q, "%d,%d,%d:%d", &m, &n, &k, &c) == 4 && m == M && n == N && k == K) return c;
@@ -1278,13 +1272,13 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
     // the UNet's 320 -> 4 output convolution is one 128-row block per CU walking 45 K tiles behind a 2-slot ring: 64-row tiles with
     // a 4-slot ring (two blocks per CU, three tiles in flight) take 20 us where it took 33 in the step; with thousands of tiles
     // (the decoder's 128 -> 3 at 512 x 512) the 128-row tile stays ahead (277 vs 329 us).  Bitwise the same results either way.
-    static const int thin = getenv("TSD_GEMM_THIN_CFG") ? atoi(getenv("TSD_GEMM_THIN_CFG")) : 0;
+    const int thin = o.thin_cfg;
     if (thin) return thin;
     return (long long)ceil_div(M, 128) * batch <= 1024 ? 24 : 4;
   }
   {
     int sk_cfg = 0;
-    if (splitk_plan(M, N, K, batch, rps, &sk_cfg) > 1) return sk_cfg;
+    if (splitk_plan(o, M, N, K, batch, rps, &sk_cfg) > 1) return sk_cfg;
   }
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
@@ -1297,7 +1291,7 @@ static int choose_cfg(int M, int N, int K, int batch, bool conv, int rps = 0) {
   //  * fewer tiles than that: 64-row tiles with 3 ring slots, 4 when K is long.
   const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, BN) * batch;
   const long long t256 = (long long)ceil_div(M, 256) * ceil_div(N, BN) * batch;
-  static const int tune = getenv("TSD_GEMM_TUNE") ? atoi(getenv("TSD_GEMM_TUNE")) : 15;  // A/B switch for the two rules below
+  const int tune = o.tune;  // A/B switch for the rules below
   // Round 3: the staggered wave-specialised 256-row tiles (51 / 53: 8 compute waves in two groups + 4 loader waves) where a
   // 256-row tiling gives every CU whole tiles - measured -5...-10 % against configurations 0 / 2 / 11 on these shapes
   // (profiles/r03_loader_waves_ab.txt); TSD_GEMM_TUNE bit 2 turns them off.  Results are bitwise those of every other tile.
@@ -1335,10 +1329,10 @@ static void cfg_wave_tile(int id, int* bmw, int* bnw) {
 }
 // EPI_GNSTATS geometry for a launch of this shape: slabs per sample (rows_per_sample / wave rows), or 0 when the tile
 // it would run with cannot emit statistics for `groups` groups over N channels.
-int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sample, int groups) {
+int gemm_gnstats_slabs(const tsd_ctx* ctx, int M, int N, int K, int batch, int conv, int rows_per_sample, int groups) {
   if (groups <= 0 || N % groups || (N & 7) || batch != 1) return 0;
   int bmw, bnw;
-  cfg_wave_tile(choose_cfg(M, N, K, batch, conv != 0, rows_per_sample), &bmw, &bnw);
+  cfg_wave_tile(choose_cfg(ctx->opt, M, N, K, batch, conv != 0, rows_per_sample), &bmw, &bnw);
   const int cpg = N / groups;
   if (!bmw || bnw % cpg || rows_per_sample % bmw || M % rows_per_sample) return 0;
   return rows_per_sample / 32;  // one slab per 32-row epilogue pass, independent of the tile shape
@@ -1346,13 +1340,16 @@ int gemm_gnstats_slabs(int M, int N, int K, int batch, int conv, int rows_per_sa
 
 template <bool CONV>
 static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
-  int id = g_force_cfg >= 0 ? g_force_cfg : (k.splitk > 1 ? k.sk_cfg : choose_cfg(k.M, k.N, k.K, batch, CONV));
+  const TsdOptions& o = ctx->opt;
+  const int force_cfg = o.force_cfg;
+  int id = force_cfg >= 0 ? force_cfg : (k.splitk > 1 ? k.sk_cfg : choose_cfg(o, k.M, k.N, k.K, batch, CONV));
   // halo-x measured: -3...5 % on the 128x128-tile convs of the VAE (N = 128 / 256 / 512), nothing on the 128x160 ones (TSD_CONV_HALO=2 turns those on too)
-  if (CONV && g_force_cfg < 0 && hx_eligible(k) && (id == 2 || (id == 0 && hx_mode() >= 2))) id += 30;
+  // (the halo-x K order addresses W row-major: a launch that reads the K-tile-major weight copy keeps its plain tile)
+  if (CONV && force_cfg < 0 && k.w_kts == 128u && hx_eligible(o, k) && (id == 2 || (id == 0 && o.conv_halo >= 2))) id += 30;
   // the fused-skip variant of the 128x128 two-blocks-per-CU tile spills (48 B of scratch per lane); its 64-row sibling does not: the
   // decoder's 256 -> 128 residual block at 512 x 512 (K = 1152 + 256) runs 1.18 ms instead of 1.35 (in-step sweep), same bits
-  if (CONV && g_force_cfg < 0 && k.Cin1 > 0 && id == 2) id = 3;
-  if ((id == 30 || id == 32) && !(CONV && hx_shape_ok(k))) TSD_FAIL(TSD_E_ARG, "gemm: halo-x tile configuration %d on an ineligible problem", id);
+  if (CONV && force_cfg < 0 && k.Cin1 > 0 && id == 2) id = 3;
+  if ((id == 30 || id == 32) && !(CONV && hx_shape_ok(k) && k.w_kts == 128u)) TSD_FAIL(TSD_E_ARG, "gemm: halo-x tile configuration %d on an ineligible problem", id);
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
 
@@ -1367,7 +1364,7 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   const int Ho = conv ? (Hi + 2 - 3) / stride + 1 : H, Wo = conv ? (Wi + 2 - 3) / stride + 1 : W;
   const int64_t M = (int64_t)B * Ho * Wo, K = conv ? 9 * (int64_t)Cin : Cin;
   // TSD_BENCH_WROT=R: R copies of the weights used round-robin, so each launch streams cold weights like a real step
-  const int wrot = getenv("TSD_BENCH_WROT") ? std::max(1, atoi(getenv("TSD_BENCH_WROT"))) : 1;
+  const int wrot = ctx->opt.bench_wrot;
   const int64_t na = (int64_t)B * H * W * Cin, nw1 = (int64_t)N * K, nw = nw1 * wrot, nc = M * N;
   TSD_TRY(ctx_reserve_arena(ctx, (size_t)(na + nw + 2 * nc) * 2 + (size_t)std::max(na, nw1) * 4 + (size_t)N * 4 + 8192));
   ctx->arena.top = 0;
@@ -1386,7 +1383,7 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
   g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.C = C; g.ldc = N;
   if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
   // TSD_BENCH_EPI: 0 plain store, 1 bias + residual (projection / conv2 epilogue), 2 bias + GEGLU
-  const int epi_mode = getenv("TSD_BENCH_EPI") ? atoi(getenv("TSD_BENCH_EPI")) : 0;
+  const int epi_mode = ctx->opt.bench_epi;
   if (epi_mode) {
     float* bias = arena_alloc<float>(ctx, N);
     half_t* R = arena_alloc<half_t>(ctx, epi_mode == 1 ? nc : 0);
@@ -1396,11 +1393,11 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
     if (epi_mode == 1) { HIP_TRY(hipMemsetAsync(R, 0, (size_t)nc * 2, ctx->stream)); g.R = R; g.ldr = N; g.epi |= EPI_RESIDUAL; }
     else { g.epi |= EPI_GEGLU; g.ldc = N / 2; }
   }
-  g_force_cfg = cfg;
+  ctx->opt.force_cfg = cfg;
   int r = launch_gemm(ctx, g);
   if (r == TSD_OK) r = launch_gemm(ctx, g);
 #ifdef TSD_GEMM_TS
-  if (getenv("TSD_GEMM_TS")) {
+  if (ctx->opt.gemm_ts) {
     const int nblk = 1 << 16;
     unsigned long long* dts = nullptr;
     HIP_TRY(hipMalloc((void**)&dts, (size_t)nblk * 64));
@@ -1431,15 +1428,15 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
     }
   }
 #endif
-  if (r != TSD_OK) { g_force_cfg = -1; return r; }
+  if (r != TSD_OK) { ctx->opt.force_cfg = -1; return r; }
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-  const int alt = getenv("TSD_BENCH_ALTCFG") ? atoi(getenv("TSD_BENCH_ALTCFG")) : -1;  // alternate two kernels (cold I-cache probe)
+  const int alt = ctx->opt.bench_altcfg;  // alternate two kernels (cold I-cache probe)
   for (int i = 0; i < iters && r == TSD_OK; i++) {
-    if (alt >= 0) g_force_cfg = (i & 1) ? alt : cfg;
+    if (alt >= 0) ctx->opt.force_cfg = (i & 1) ? alt : cfg;
     g.Wt = Wt + (int64_t)(i % wrot) * nw1;
     r = launch_gemm(ctx, g);
   }
-  g_force_cfg = -1;
+  ctx->opt.force_cfg = -1;
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));
   float t = 0.f;
@@ -1475,11 +1472,11 @@ extern "C" int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W,
   GemmArgs g;
   g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.ldc = N;
   if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
-  g.C = C0; g_force_cfg = ref_cfg;
+  g.C = C0; ctx->opt.force_cfg = ref_cfg;
   int r = launch_gemm(ctx, g);
-  g.C = C1; g_force_cfg = cfg;
+  g.C = C1; ctx->opt.force_cfg = cfg;
   if (r == TSD_OK) r = launch_gemm(ctx, g);
-  g_force_cfg = -1;
+  ctx->opt.force_cfg = -1;
   if (r != TSD_OK) return r;
   std::vector<half_t> h0(nc), h1(nc);
   HIP_TRY(hipMemcpyAsync(h0.data(), C0, nc * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -1535,18 +1532,18 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   if (a.Vt) {
     const int BNt = (a.N % 160 == 0) ? 160 : 128;
     if (a.conv || a.batch != 1 || (a.epi & ~(EPI_BIAS_N)) || a.N % 8 || a.N <= 16 || a.vt_n0 <= 0 || a.vt_n0 % BNt || a.vt_S <= 0 || a.vt_S % 8 ||
-        a.M % a.vt_S || a.vt_ld < a.vt_S || a.vt_ld % 8 || g_force_cfg >= 0)
+        a.M % a.vt_S || a.vt_ld < a.vt_S || a.vt_ld % 8 || ctx->opt.force_cfg >= 0)
       TSD_FAIL(TSD_E_ARG, "gemm: transposed tail (n0 %d, rows per sample %d, pitch %d) does not fit this launch", a.vt_n0, a.vt_S, a.vt_ld);
   }
   if (a.epi & EPI_GNSTATS) {
     if ((a.epi & (EPI_GEGLU | EPI_OUT_F32)) || !a.gn_part ||
-        a.gn_nslab != gemm_gnstats_slabs(a.M, a.N, a.K, a.batch, a.conv, a.gn_rows_per_sample, a.gn_groups) || a.gn_nslab <= 0)
+        a.gn_nslab != gemm_gnstats_slabs(ctx, a.M, a.N, a.K, a.batch, a.conv, a.gn_rows_per_sample, a.gn_groups) || a.gn_nslab <= 0)
       TSD_FAIL(TSD_E_ARG, "gemm: GroupNorm statistics requested for a shape/tile that cannot emit them");
   }
   // split-K workspace (arena: the planning pass sees the same allocation) and the per-context arrival flags
   float* sk_ws = nullptr;
   int sk_cfg = 0;
-  const int ways = g_force_cfg < 0 ? splitk_plan(a.M, a.N, a.K, a.batch, a.rows_per_sample_hint, &sk_cfg) : 1;
+  const int ways = ctx->opt.force_cfg < 0 ? splitk_plan(ctx->opt, a.M, a.N, a.K, a.batch, a.rows_per_sample_hint, &sk_cfg) : 1;
   const bool splitk = ways > 1;
   if (splitk) {
     const int BN = (a.N % 160 == 0) ? 160 : 128, BM = (sk_cfg == 7 || sk_cfg == 10 || sk_cfg == 6 || sk_cfg == 9) ? 64 : 128;
@@ -1566,7 +1563,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   k.A2 = a.A2; k.Wt1 = a.Wt1; k.lda2 = a.lda2; k.Cin1 = a.conv ? a.Cin1 : 0; k.Cin2 = a.conv ? a.Cin2 : 0; k.ldw1 = a.ldw1;
   k.epi = a.epi; k.tiles_n = 0; k.out_scale = a.out_scale;
   k.w_kts = a.w_kts ? (unsigned)a.w_kts : 128u;
-  if (a.w_kts && (a.ldw != 64 || a.w_kts < a.N * 128 || hx_mode() > 0)) TSD_FAIL(TSD_E_ARG, "gemm: K-tile-major W needs ldw = 64 and a tile stride >= N * 128");
+  if (a.w_kts && (a.ldw != 64 || a.w_kts < a.N * 128)) TSD_FAIL(TSD_E_ARG, "gemm: K-tile-major W needs ldw = 64 and a tile stride >= N * 128");
   k.gn_part = a.gn_part; k.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 1; k.gn_G = a.gn_groups; k.gn_hw = a.gn_rows_per_sample;
   k.gn_nslab = a.gn_nslab;
   k.vt = a.Vt; k.vt_sB = a.vt_sB; k.vt_n0 = a.vt_n0; k.vt_ld = a.vt_ld; k.vt_S = a.vt_S;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void gn_finish_groups(const GnK& p, int b, int g0, in
   if (g < p.G)
 #pragma unroll 4
     for (int s = sl; s < p.nslab; s += 8) {
-      if (p.comb <= 1) {
+      if (p.comb <= 1 && !p.partial1) {
         const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
         t1 += (double)o[0];
         t2 += (double)o[1];
@@ -282,8 +282,7 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   // stats pass: 2*GN_UNROLL pixels per thread, at most 512 slabs per sample ; apply pass: GN_UNROLL pixels per thread
   k.slab_pixels = std::max(2 * GN_UNROLL * PL, ceil_div(HW, 64));  // <= 64 slabs: every apply block re-reduces them
   k.nslab = ceil_div(HW, k.slab_pixels);
-  static const int apply_mult = getenv("TSD_GN_APPLY_MULT") ? atoi(getenv("TSD_GN_APPLY_MULT")) : 2;
-  k.apply_pixels = apply_mult * GN_UNROLL * PL;
+  k.apply_pixels = (ctx->opt.gn_apply_mult > 0 ? ctx->opt.gn_apply_mult : 2) * GN_UNROLL * PL;
   // statistics already emitted by the producer's epilogue (EPI_GNSTATS, same [B][nslab][G][2] layout): no partial pass
   // composite: the statistics are sums of the producers' finer-grained partials (two concat sources, or one source emitted for a
   // finer grouping) - no statistics pass over the concatenated tensor

@@ -164,7 +164,6 @@ extern "C" int tsd_model_mark_loaded(tsd_model* m) {
   return TSD_OK;
 }
 
-static bool tml_mib_on() { return !(getenv("TSD_LIN_W_TM") && atoi(getenv("TSD_LIN_W_TM")) == 0); }
 // derived device buffers (not part of the broadcast blob: every rank rebuilds them from the packed weights)
 static int model_build_derived(tsd_model* m) {
   tsd_ctx* ctx = m->ctx;
@@ -196,10 +195,10 @@ static int model_build_derived(tsd_model* m) {
   const bool cin_ok = cin.w && cin.k == 3 && cin.I > 0 && 9 * cin.I <= 64 && cin.Ipad == 64;
   const size_t cin_b = cin_ok ? ((size_t)cin.Opad * 64 * sizeof(half_t) + 255) & ~size_t(255) : 0;
   // weight-heavy 3x3 convs (>= TSD_CONV_W_TM MiB of weights; 0 = off): K-tile-major copies
-  static const int tm_mib = getenv("TSD_CONV_W_TM") ? atoi(getenv("TSD_CONV_W_TM")) : 2;  // measured: +0.3 % headline, +0.6 % full-size UNet (profiles/r03_conv_w_tile_major_ab.txt)
+  const int tm_mib = ctx->opt.conv_w_tm_mib;  // measured: +0.3 % headline, +0.6 % full-size UNet (profiles/r03_conv_w_tile_major_ab.txt)
   // linear layers / 1x1 convs: TSD_LIN_W_TM = 0 turns them off, TSD_LIN_W_TM_KIB sets the size threshold (default 1 MiB; with 512 KiB the
   // 800-KB 640 x 640 projections of the 32x32 level join in: measured equal, 205.65 vs 205.60 steps/s)
-  static const int tml_kib = getenv("TSD_LIN_W_TM_KIB") ? atoi(getenv("TSD_LIN_W_TM_KIB")) : 1024;
+  const int tml_kib = ctx->opt.lin_w_tm_kib;
   const size_t tml_bytes = (size_t)(tml_kib > 0 ? tml_kib : 1024) << 10;
   std::vector<ConvW*> tm;
   size_t tm_b = 0;
@@ -213,13 +212,13 @@ static int model_build_derived(tsd_model* m) {
     for (auto& cv : m->unet.conv)
       if (cv.w && cv.k == 3 && (size_t)cv.Opad * 9 * cv.Ipad * 2 >= (size_t)tm_mib << 20) { tm.push_back(&cv); tm_b += (((size_t)cv.Opad * 9 * cv.Ipad * 2) + 255) & ~size_t(255); }
   }
-  if (tm_mib > 0 && tml_mib_on())
+  if (tm_mib > 0 && ctx->opt.lin_w_tm != 0)
     for (auto& a : m->unet.attn)
       if (a.C && !(attn_tail_weights_ok(a) && attn_head_weights_ok(a)))
         for (ConvW* c : {&a.conv_in, &a.conv_out})
           if (c->w && c->k == 1 && c->Ipad % 64 == 0 && (size_t)c->Opad * c->Ipad * 2 >= tml_bytes) { tm.push_back(c); tm_b += (((size_t)c->Opad * c->Ipad * 2) + 255) & ~size_t(255); }
   // ... and of the attention blocks' linear layers (TSD_LIN_W_TM MiB; the 64x64-level blocks read theirs through the fused kernels' streams)
-  static const int tml_mib = getenv("TSD_LIN_W_TM") ? atoi(getenv("TSD_LIN_W_TM")) : 1;  // measured: +0.4 % headline, +0.6 % full-size UNet (profiles/r03_lin_w_tile_major_ab.txt)
+  const int tml_mib = ctx->opt.lin_w_tm;  // measured: +0.4 % headline, +0.6 % full-size UNet (profiles/r03_lin_w_tile_major_ab.txt)
   std::vector<LinW*> tml;
   if (tml_mib > 0)
     for (auto& a : m->unet.attn)

@@ -15,6 +15,40 @@ void tsd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// the ONLY place the library reads its tuning switches from the environment (one pass per context, at tsd_ctx_create)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+void options_from_env(TsdOptions& o) {
+  o.qkv_fuse = env_int("TSD_QKV_FUSE", o.qkv_fuse);
+  o.res_fuse_skip = env_int("TSD_RES_FUSE_SKIP", o.res_fuse_skip);
+  o.gn_composite = env_int("TSD_GN_COMPOSITE", o.gn_composite);
+  o.conv_in_im2col = env_int("TSD_CONV_IN_IM2COL", o.conv_in_im2col);
+  o.chain = env_int("TSD_CHAIN", o.chain) ? 1 : 0;
+  o.conv_w_tm_mib = env_int("TSD_CONV_W_TM", o.conv_w_tm_mib);
+  o.lin_w_tm = env_int("TSD_LIN_W_TM", o.lin_w_tm);
+  o.lin_w_tm_kib = env_int("TSD_LIN_W_TM_KIB", o.lin_w_tm_kib);
+  { const int q = env_int("TSD_ATTN_QB", o.attn_qb); if (q == 1 || q == 2) o.attn_qb = q; }
+  o.attn_xcd = env_int("TSD_ATTN_XCD", o.attn_xcd);
+  o.xcdn = env_int("TSD_GEMM_XCDN", o.xcdn);
+  o.conv_halo = env_int("TSD_CONV_HALO", o.conv_halo);
+  o.splitk = env_int("TSD_GEMM_SPLITK", o.splitk);
+  o.splitk_mink = env_int("TSD_GEMM_SPLITK_MINK", o.splitk_mink);
+  o.splitk_tiles = env_int("TSD_GEMM_SPLITK_TILES", o.splitk_tiles);
+  o.splitk_small = env_int("TSD_GEMM_SPLITK_SMALL", o.splitk_small);
+  o.splitk_wide = env_int("TSD_GEMM_SPLITK_WIDE", o.splitk_wide);
+  o.splitk_ring4 = env_int("TSD_GEMM_SPLITK_RING4", o.splitk_ring4);
+  o.splitk_big = env_int("TSD_GEMM_SPLITK_BIG", o.splitk_big);
+  o.sk_cfg = env_int("TSD_GEMM_SK_CFG", o.sk_cfg);
+  o.thin_cfg = env_int("TSD_GEMM_THIN_CFG", o.thin_cfg);
+  o.tune = env_int("TSD_GEMM_TUNE", o.tune);
+  if (const char* ov = getenv("TSD_GEMM_CFG_OVERRIDE")) { strncpy(o.cfg_override, ov, sizeof(o.cfg_override) - 1); o.cfg_override[sizeof(o.cfg_override) - 1] = 0; }
+  o.gn_apply_mult = env_int("TSD_GN_APPLY_MULT", o.gn_apply_mult);
+  o.debug_occ = getenv("TSD_DEBUG_OCC") ? 1 : 0;
+  o.bench_wrot = env_int("TSD_BENCH_WROT", o.bench_wrot); if (o.bench_wrot < 1) o.bench_wrot = 1;
+  o.bench_epi = env_int("TSD_BENCH_EPI", o.bench_epi);
+  o.bench_altcfg = env_int("TSD_BENCH_ALTCFG", o.bench_altcfg);
+  o.gemm_ts = getenv("TSD_GEMM_TS") ? 1 : 0;
+}
+
 extern "C" int tsd_version(void) { return TSD_VERSION; }
 extern "C" const char* tsd_last_error(void) { return g_err; }
 
@@ -41,9 +75,12 @@ extern "C" int tsd_ctx_create(int device, tsd_ctx** out) {
     TSD_FAIL(TSD_E_HIP, "tsd_ctx_create: device %d is %s; libtsd is built for gfx950 only", device, prop.gcnArchName);
   tsd_ctx* c = new tsd_ctx();
   c->device = device;
+  options_from_env(c->opt);
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc((void**)&c->status, 16 * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(c->status, 0, 16 * sizeof(int), c->stream));
   HIP_TRY(hipMalloc((void**)&c->zeros, 4096));
   HIP_TRY(hipMemsetAsync(c->zeros, 0, 4096, c->stream));
   HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)(c->zeros + 1024), 0x3C00, 64, c->stream));  // 64 halves of 1.0 (attention row sums)
@@ -59,6 +96,7 @@ extern "C" int tsd_ctx_destroy(tsd_ctx* c) {
   if (c->arena.base) hipFree(c->arena.base);
   if (c->staging) hipFree(c->staging);
   if (c->zeros) hipFree(c->zeros);
+  if (c->status) hipFree(c->status);
   if (c->sk_flags) hipFree(c->sk_flags);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
@@ -82,11 +120,37 @@ int ctx_check_splitk(tsd_ctx* c) {
   return TSD_OK;
 }
 
+// call after a stream synchronize
+int ctx_check_status(tsd_ctx* c) {
+  TSD_TRY(ctx_check_splitk(c));
+  if (!c->status) return TSD_OK;
+  int n = 0;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(&n, c->status, sizeof(int), hipMemcpyDeviceToHost));
+  if (n != 0) {
+    const int zero = 0;  // reported once, then cleared
+    (void)hipMemcpy(c->status, &zero, sizeof(int), hipMemcpyHostToDevice);
+    TSD_FAIL(TSD_E_NONFINITE, "%d non-finite value(s) (inf / NaN) reached a tensor that leaves the device since the last clean "
+             "synchronisation: an fp16 activation overflowed (|x| > 65504) or an input was not finite; the outputs are not "
+             "the reference's (BASELINE.md section 4: supported dynamic range)", n);
+  }
+  return TSD_OK;
+}
+// Non-finite values written to caller-visible tensors on this context since the last report / reset (synchronises the stream).
+extern "C" int tsd_debug_nonfinite_count(tsd_ctx* c, int reset) {
+  if (!c || !c->status) return -1;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  int n = 0;
+  if (hipMemcpy(&n, c->status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset) { const int zero = 0; if (hipMemcpy(c->status, &zero, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1; }
+  return n;
+}
+
 extern "C" int tsd_ctx_synchronize(tsd_ctx* c) {
   if (!c) TSD_FAIL(TSD_E_ARG, "tsd_ctx_synchronize: ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return ctx_check_splitk(c);
+  return ctx_check_status(c);
 }
 
 extern "C" int tsd_ctx_timer_start(tsd_ctx* c) {

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtsd.so")
 
-TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE = 0, -1, -2, -3, -4, -5, -6
+TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE, TSD_E_NONFINITE = 0, -1, -2, -3, -4, -5, -6, -7
 # Kernel arguments in device memory instead of host-coherent memory: every kernel starts by reading its ~200 B argument
 # block, and fetching it across the host link costs ~2 us per launch (measured: 169 -> 177 steps/s).  The HIP runtime
 # reads the switch when it initialises, so it goes into the environment as soon as this package is imported - before
@@ -107,14 +107,15 @@ def _declare(l):
         "tsd_flop_count": ([i, i, i], C.c_double),
         "tsd_debug_splitk_errors": ([vp], i),
         "tsd_debug_xcd_round_robin": ([], i),
-        "tsd_debug_set_fused_attention": ([i], i),
+        "tsd_debug_nonfinite_count": ([vp, i], i),
+        "tsd_debug_set_fused_attention": ([vp, i], i),
         "tsd_debug_gemm_bench": ([vp, i, i, i, i, i, i, i, i, i, i, fp], i),
         "tsd_debug_attn_bench": ([vp, i, i, i, i, i, i, fp], i),
         "tsd_debug_attn_exact_passes": ([vp, i], i),
-        "tsd_debug_set_attn_qb": ([i], i),
-        "tsd_debug_set_attn_diag": ([i], i),
-        "tsd_debug_set_res_fuse_skip": ([i], i),
-        "tsd_debug_set_qkv_fuse": ([i], i),
+        "tsd_debug_set_attn_qb": ([vp, i], i),
+        "tsd_debug_set_attn_diag": ([vp, i], i),
+        "tsd_debug_set_res_fuse_skip": ([vp, i], i),
+        "tsd_debug_set_qkv_fuse": ([vp, i], i),
         "tsd_debug_mfma_sustained": ([vp, C.c_float, fp, fp], i),
         "tsd_debug_gemm_check": ([vp, i, i, i, i, i, i, i, i, i, i, fp, fp], i),
     }

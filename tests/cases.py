@@ -554,6 +554,25 @@ class _TM:
         return t.forward(i["t"])
 
 
+@case("unet_output_layer", tol=TOL_BLOCK, tol_max=TOL_BLOCK_MAX)
+class _OL:
+    """`UNet_Output_Layer` diffusion.mojo:275-291 on its own: GroupNorm(320 groups over 320 channels = a
+    per-channel instance norm) -> SiLU -> Conv2D(320, 4, 3, padding 1)."""
+    @staticmethod
+    def build():
+        return dict(x=randn(120, 320, 16, 16) * 1.7 + 0.3, w=_w(121, 4, 320, 3, 3), b=randn(122, 4) * 0.1)
+
+    @staticmethod
+    def oracle(i):
+        return models.unet_output_layer({"final.layer2.kernel": i["w"], "final.layer2.bias": i["b"]}, i["x"], "final")
+
+    @staticmethod
+    def device(tsd, i):
+        o = tsd.UNet_Output_Layer(320, 4)
+        o.layer2.kernel, o.layer2.bias = i["w"], i["b"]
+        return o.forward(i["x"])
+
+
 # cases whose oracle output is stored in tests/golden/golden.npz (kept < 1 MB)
 GOLDEN = ["conv3x3_64_64_s1", "conv3x3_320_320_s2", "conv3x3_ragged", "conv3x3_4_320", "conv3x3_320_4", "conv1x1_4_4",
           "conv3x3_pad0_s2", "pad_asymmetric", "groupnorm_320_32", "groupnorm_320_320", "groupnorm_partial_channels",

@@ -606,15 +606,15 @@ def test_fused_attention_blocks_match_unfused_graph_at_full_size(gpu_ctx, tsd_mo
     from tsd._lib import lib
     lat, ctx = _inputs(8, 64, tag=780)
     temb = np.stack([ops.time_embedding(t) for t in (980.0, 860.0, 700.0, 500.0, 300.0, 120.0, 20.0, 0.0)])
-    old = lib().tsd_debug_set_fused_attention(1)
+    old = lib().tsd_debug_set_fused_attention(gpu_ctx.h, 1)
     try:
         fused = diffusion.forward(lat, ctx, temb)
         np.testing.assert_array_equal(diffusion.forward(lat, ctx, temb), fused)
         np.testing.assert_array_equal(diffusion.forward(lat[3], ctx[3], temb[3]), fused[3])
-        lib().tsd_debug_set_fused_attention(0)
+        lib().tsd_debug_set_fused_attention(gpu_ctx.h, 0)
         plain = diffusion.forward(lat, ctx, temb)
     finally:
-        lib().tsd_debug_set_fused_attention(old)
+        lib().tsd_debug_set_fused_attention(gpu_ctx.h, old)
     assert np.isfinite(fused).all() and np.isfinite(plain).all()
     err = rel_l2(fused, plain)
     print(f"[parity] fused vs op-by-op attention blocks, B=8 L=64: rel_l2 = {err:.3e}")

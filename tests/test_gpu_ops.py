@@ -122,16 +122,16 @@ def test_attention_second_reference_keeps_self_peaked_rows_in_the_optimistic_pas
     i = c.build()
     ref = np.asarray(c.oracle(i), dtype=np.float32)
     n_wg = 8 * ((320 + 127) // 128)  # heads x 128-query workgroups (S = 320 runs the 32-queries-per-wave variant)
-    prev = L.tsd_debug_set_attn_diag(0)
+    prev = L.tsd_debug_set_attn_diag(gpu_ctx.h, 0)
     try:
         L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
         y0 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
         n0 = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
-        L.tsd_debug_set_attn_diag(1)
+        L.tsd_debug_set_attn_diag(gpu_ctx.h, 1)
         y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
         n1 = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
     finally:
-        L.tsd_debug_set_attn_diag(prev)
+        L.tsd_debug_set_attn_diag(gpu_ctx.h, prev)
     print(f"[parity] self-peaked scores: exact repeats {n0}/{n_wg} workgroups with the tile-0 reference, {n1}/{n_wg} with the own-block reference")
     assert n0 >= n_wg // 2, n0          # the round-2 reference repeats (at least the workgroups beyond key tile 0)
     assert n1 == 0, n1                  # the second reference keeps every row inside fp16
@@ -150,13 +150,13 @@ def test_fused_skip_conv_equals_separate_skip_gemm(gpu_ctx, tsd_mod, name):
     c = CASES[name]
     i = c.build()
     ref = np.asarray(c.oracle(i), dtype=np.float32)
-    prev = L.tsd_debug_set_res_fuse_skip(0)
+    prev = L.tsd_debug_set_res_fuse_skip(gpu_ctx.h, 0)
     try:
         y0 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
-        L.tsd_debug_set_res_fuse_skip(1)
+        L.tsd_debug_set_res_fuse_skip(gpu_ctx.h, 1)
         y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
     finally:
-        L.tsd_debug_set_res_fuse_skip(prev)
+        L.tsd_debug_set_res_fuse_skip(gpu_ctx.h, prev)
     assert_close(y0, ref, c.tol, c.tol_max, what=f"{name}, separate skip GEMM")
     assert_close(y1, ref, c.tol, c.tol_max, what=f"{name}, skip fused into conv2")
     d = rel_l2(y1, y0)
@@ -177,13 +177,13 @@ def test_fused_qkv_projection_equals_two_launches(gpu_ctx, tsd_mod, name):
     c = CASES[name]
     i = c.build()
     ref = np.asarray(c.oracle(i), dtype=np.float32)
-    prev = L.tsd_debug_set_qkv_fuse(0)
+    prev = L.tsd_debug_set_qkv_fuse(gpu_ctx.h, 0)
     try:
         y0 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
-        L.tsd_debug_set_qkv_fuse(1)
+        L.tsd_debug_set_qkv_fuse(gpu_ctx.h, 1)
         y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
     finally:
-        L.tsd_debug_set_qkv_fuse(prev)
+        L.tsd_debug_set_qkv_fuse(gpu_ctx.h, prev)
     assert_close(y0, ref, c.tol, c.tol_max, what=f"{name}, two launches")
     assert_close(y1, ref, c.tol, c.tol_max, what=f"{name}, fused q/k/v projection")
     d = rel_l2(y1, y0)
@@ -211,16 +211,16 @@ def test_attention_64_queries_per_wave_is_bitwise_the_128_query_workgroup(gpu_ct
     its rows), so there the two only agree to rounding; both must match the oracle."""
     from tsd._lib import lib
     L = lib()
-    prev = L.tsd_debug_set_attn_qb(1)
+    prev = L.tsd_debug_set_attn_qb(gpu_ctx.h, 1)
     L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
     try:
         for name in ("self_attention_d40", "self_attention_d40_ragged", "self_attention_d40_rising_scores",
                      "self_attention_d40_falling_scores", "cross_attention_d40_T77"):
             c = CASES[name]
             i = c.build()
-            L.tsd_debug_set_attn_qb(1)
+            L.tsd_debug_set_attn_qb(gpu_ctx.h, 1)
             y1 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
-            L.tsd_debug_set_attn_qb(2)
+            L.tsd_debug_set_attn_qb(gpu_ctx.h, 2)
             y2 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
             if "rising" in name:
                 assert L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1) > 0
@@ -230,7 +230,7 @@ def test_attention_64_queries_per_wave_is_bitwise_the_128_query_workgroup(gpu_ct
                 np.testing.assert_array_equal(y1, y2, err_msg=name)
             assert_close(y2, np.asarray(c.oracle(i), dtype=np.float32), c.tol, c.tol_max, what=name + " (QB=2)")
     finally:
-        L.tsd_debug_set_attn_qb(prev)
+        L.tsd_debug_set_attn_qb(gpu_ctx.h, prev)
 
 
 @pytest.mark.parametrize("B,H,Cin,N,cfg,ref", [(2, 64, 64, 160, 30, 0), (2, 64, 640, 320, 30, 0), (1, 128, 128, 128, 32, 2),
