@@ -154,14 +154,34 @@ def test_heavy_tailed_weights_vae_last_level(gpu_ctx, tsd_mod):
 
 
 # ---- beyond the range: loud, never silent ------------------------------------------------------------------------------------------
-def test_conv_overflow_is_reported_not_silent(gpu_ctx, tsd_mod):
+def test_conv_op_beyond_fp16_is_still_exact(gpu_ctx, tsd_mod):
+    """The op-level Conv2D writes its result as fp32 straight from the accumulator (no fp16 store on the way out), so an output
+    beyond the fp16 range is not an overflow at all: it is the reference's value, and nothing is reported."""
+    from tsd._lib import lib
+    L = lib()
+    L.tsd_debug_nonfinite_count(gpu_ctx.h, 1)
+    c, x, ref = _conv_at(tsd_mod, 2.0e5)
+    assert np.isfinite(ref).all() and np.abs(ref).max() > FP16_MAX
+    assert_close(np.asarray(c.forward(x)), ref, TOL_OP, TOL_OP_MAX, what="conv3x3 64->64, max |y| = 2e5 (fp32 output)")
+    assert L.tsd_debug_nonfinite_count(gpu_ctx.h, 0) == 0
+
+
+def test_block_overflow_is_reported_not_silent(gpu_ctx, tsd_mod):
+    """A residual block whose 1x1 skip term (diffusion.mojo:70-72) leaves the fp16 range: the reference's fp32 result is finite,
+    the block's fp16 output tensor cannot hold it -> TSD_E_NONFINITE from the synchronous call, never silent inf / NaN."""
     from tsd._lib import TSD_E_NONFINITE, lib
     L = lib()
     assert L.tsd_debug_nonfinite_count(gpu_ctx.h, 1) >= 0
-    c, x, ref = _conv_at(tsd_mod, 2.0e5)           # the reference's fp32 result is finite; fp16 cannot store it
+    c = CASES["unet_res_320_640"]
+    i = c.build()
+    i["x"] = i["x"] * np.float32(3.0e4 / np.abs(i["x"]).max())      # representable input ...
+    P = dict(i["P"])
+    P["r.layer6.kernel"] = P["r.layer6.kernel"] * np.float32(20.0)  # ... times an amplifying skip convolution
+    i["P"] = P
+    ref = np.asarray(c.oracle(i), np.float32)
     assert np.isfinite(ref).all() and np.abs(ref).max() > FP16_MAX
     with pytest.raises(tsd_mod.TsdError) as e:
-        c.forward(x)
+        c.device(tsd_mod, i)
     assert e.value.code == TSD_E_NONFINITE, e.value
     assert "non-finite" in str(e.value)
     assert L.tsd_debug_nonfinite_count(gpu_ctx.h, 0) == 0          # reported once, then cleared
