@@ -233,6 +233,14 @@ def main():
             bcast_how = ("rccl broadcast of the packed blobs from rank 0 (in place, zero-copy view of the blob)" if backend == "nccl"
                          else f"{backend} broadcast of the packed blobs from rank 0 through host memory")
 
+    # derived device buffers (K-tile-major weight copies, fused-kernel weight streams): rebuilt on EVERY rank from the packed
+    # weights after the broadcast - timed here so a multi-GPU run shows what start-up costs beside the broadcast itself
+    t_d = time.time()
+    unet.model.prepare()
+    if dec is not None:
+        dec.model.prepare()
+    derived_s = time.time() - t_d
+
     # synthetic inputs: global batch of world*B independent prompts, this rank's contiguous shard
     lo, hi = shard_range(world * B, rank, world)
     assert hi - lo == B
@@ -276,9 +284,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # stragglers: every rank's own rate from its device events, min and max over ranks (a real 8-GPU run shows them here)
-        rr = torch.tensor([K / (ev_ms * 1e-3), -K / (ev_ms * 1e-3)], dtype=torch.float64, device=dd)
+        rr = torch.tensor([K / (ev_ms * 1e-3), -K / (ev_ms * 1e-3), derived_s], dtype=torch.float64, device=dd)
         dist.all_reduce(rr, op=dist.ReduceOp.MAX)
         rank_rate = (-float(rr[1].item()), float(rr[0].item()))
+        derived_s = float(rr[2].item())  # the slowest rank's rebuild
     out_lat = sess.latents()
     finite = bool(np.isfinite(out_lat).all())
 
@@ -478,7 +487,7 @@ def main():
             "event_ms_per_step": round(ev_ms / K, 4), "output_finite": finite,
             "frac_of_fp16_mfma_peak_whole_step": round(whole_frac, 4),
             "per_rank_steps_per_s": {"min": round(rank_rate[0], 3), "max": round(rank_rate[1], 3)},
-            "weight_broadcast_s": round(bcast_s, 4), "weight_broadcast_bytes": bcast_bytes, "weight_broadcast": bcast_how,
+            "weight_broadcast_s": round(bcast_s, 4), "derived_buffers_s": round(derived_s, 4), "weight_broadcast_bytes": bcast_bytes, "weight_broadcast": bcast_how,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -207,6 +207,10 @@ int tsd_model_init_random(tsd_model* m, uint64_t seed);
 /* The packed fp16/fp32 weight blob (one device allocation) - what multi-GPU broadcasts. */
 int tsd_model_packed_blob(tsd_model* m, void** device_ptr, size_t* bytes);
 int tsd_model_mark_loaded(tsd_model* m); /* after an external write (RCCL broadcast) into the blob */
+/* Build the model's derived device buffers now (K-tile-major weight copies, the fused kernels' weight streams, im2col input
+ * weights - rebuilt per rank, never broadcast) and wait for them; otherwise the first forward builds them.  Lets a multi-GPU host
+ * time that step next to the broadcast (bench.py `derived_buffers_s`).  TSD_E_STATE if a used parameter was never set. */
+int tsd_model_prepare(tsd_model* m);
 
 /* `Diffusion.forward` diffusion.mojo:309-318, batched.  latents [B,4,L,L], context [B,T,768],
  * time_emb [B,320] (= get_time_embedding(t) per sample) -> out [B,4,L,L]. */

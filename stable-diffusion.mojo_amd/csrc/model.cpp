@@ -301,6 +301,14 @@ int model_check_ready(tsd_model* m) {
   return TSD_OK;
 }
 
+extern "C" int tsd_model_prepare(tsd_model* m) {
+  if (!m) TSD_FAIL(TSD_E_ARG, "NULL model");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  TSD_TRY(model_check_ready(m));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  return TSD_OK;
+}
+
 ConvW model_conv(const tsd_model* m, const std::string& prefix) {
   ConvW w;
   auto it = m->index.find(prefix + ".kernel");

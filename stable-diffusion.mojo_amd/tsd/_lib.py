@@ -85,7 +85,7 @@ def _declare(l):
         "tsd_model_param_info": ([i, i, C.c_char_p, i, C.POINTER(i64), C.POINTER(i), C.POINTER(i), fp], i),
         "tsd_model_create": ([vp, i, pp], i), "tsd_model_destroy": ([vp], i),
         "tsd_model_set_param": ([vp, i, fp, i64], i), "tsd_model_init_random": ([vp, u64], i),
-        "tsd_model_packed_blob": ([vp, pp, C.POINTER(sz)], i), "tsd_model_mark_loaded": ([vp], i),
+        "tsd_model_packed_blob": ([vp, pp, C.POINTER(sz)], i), "tsd_model_mark_loaded": ([vp], i), "tsd_model_prepare": ([vp], i),
         "tsd_diffusion_forward": ([vp, fp, fp, fp, i, i, i, fp], i),
         "tsd_decoder_forward": ([vp, fp, i, i, fp], i),
         "tsd_encoder_forward": ([vp, fp, fp, i, i, fp], i),

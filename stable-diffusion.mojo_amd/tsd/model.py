@@ -67,6 +67,10 @@ class Model:
     def mark_loaded(self):
         check(lib().tsd_model_mark_loaded(self.h))
 
+    def prepare(self):
+        """Build the derived device buffers now (per rank, after the weights are in place) and wait for them."""
+        check(lib().tsd_model_prepare(self.h))
+
     def close(self):
         if self.h:
             lib().tsd_model_destroy(self.h)

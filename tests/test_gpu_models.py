@@ -642,6 +642,7 @@ def test_bench_two_ranks_on_one_gpu(gpu_ctx):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["output_finite"] and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["weight_broadcast"].startswith("gloo broadcast") and d["weight_broadcast_bytes"] > 5e8
+    assert d["derived_buffers_s"] > 0  # per-rank rebuild of the derived weight copies, timed next to the broadcast
     bad = _run_bench_two_ranks_one_gpu({"TSD_BENCH_FAIL_BCAST": "1"}, 29542)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
