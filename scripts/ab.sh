@@ -6,7 +6,7 @@ for rep in 1 2 3; do
   for v in base new; do
     cp scripts/libtsd_$v.so $L
     if [ "$rep" = 1 ] && [ -n "${MICRO:-}" ]; then echo "== $v micro"; ITERS=50 timeout 300 python $MICRO 2>&1 | tail -n 8; fi
-    echo "== $v bench $rep"; timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-decode --no-extras 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])"
+    echo "== $v bench $rep"; timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-decode --no-extras 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['per_class_ms_per_step']['attn_tail_chain'])"
   done
 done
 cp scripts/libtsd_new.so $L

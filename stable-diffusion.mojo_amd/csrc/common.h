@@ -72,6 +72,7 @@ struct TsdOptions {
   int sk_big_graph = 0;    // slices of the long-K split launches asked for by the graph being enqueued (gemm_set_splitk_big)
   char cfg_override[512] = "";  // TSD_GEMM_CFG_OVERRIDE
   int gn_apply_mult = 2;   // TSD_GN_APPLY_MULT
+  int gn_finalize_min = 2048;  // TSD_GN_FINALIZE_MIN: slab x group partial pairs per sample from which a separate k_gn_finalize launch finishes the statistics
   int debug_occ = 0;       // TSD_DEBUG_OCC
   int bench_wrot = 1, bench_epi = 0, bench_altcfg = -1, gemm_ts = 0;  // microbenchmark only (tsd_debug_gemm_bench)
   unsigned gen = 0;        // bumped by every tsd_debug_set_* call on this context

@@ -64,9 +64,9 @@ namespace {
 constexpr int C = 320, BM = 64;
 constexpr int A_OFF = 0, A_KT = 8192;                 // A tile: 5 k-tiles x [64 rows][128 B]
 constexpr int ACT_OFF = 40960;                        // GEGLU activations: 2 k-tiles x [64][128 B]
-constexpr int RING_OFF = ACT_OFF + 16384, SLOT = 20480, NSLOT = 5;  // ring of [2 halves][160 rows][64 B] weight tiles
-constexpr int SCR_OFF = RING_OFF + NSLOT * SLOT;      // LayerNorm exchange: [64 rows][2 column waves] x (mean, M2)
-constexpr int LDS_BYTES = SCR_OFF + 1024;
+constexpr int RING_OFF = ACT_OFF + 16384, SLOT = 20480, NSLOT = 5;  // ring of [4 quarters][80 rows][64 B] weight tiles
+constexpr int SCR_OFF = RING_OFF + NSLOT * SLOT;      // LayerNorm exchange: [64 rows][4 column waves] x (mean, M2)
+constexpr int LDS_BYTES = SCR_OFF + 2048;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 // the weight stream (bytes): tiles of 32 k.  Full tiles hold 320 rows (20480 B), GEGLU-1 tiles 256 rows (16384 B).
 constexpr int TILE_FULL = 20480, TILE_G1 = 16384;
@@ -87,6 +87,31 @@ __device__ __forceinline__ float gelu_tanh_c(float x) {  // helpers/utils.mojo:1
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// An opaque use-and-redefine of a value: whatever computes it must be issued before this point and whatever consumes it after - it
+// ties side-effect-free arithmetic to its place between the MFMAs.  (A __device__ function so that the host pass never sees the "v"
+// constraint.)
+__device__ __forceinline__ unsigned pin_here(unsigned w) { asm volatile("" : "+v"(w)); return w; }
+// Reductions over the four 16-lane rows of a wave (lanes with the same lane & 15) without LDS round trips: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows of two registers; with both holding the same value, a' + b' is the pairwise
+// row sum in EVERY lane.  __shfl_xor lowers to ds_bpermute_b32 (an LDS round trip per dependent step: the LayerNorm and softmax
+// statistics are chains of four).  (The __builtin_amdgcn_permlane*_swap builtins, given the same value for both operands, came out
+// as a' + a' with hipcc 7.2 - hence the asm; s_nop 1 covers the VALU-write -> permlane hazard the assembler does not see.)
+__device__ __forceinline__ void rows_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void rows_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_sum(float v) {  // sum over the wave's four rows, in every lane
+  float a = v, b = v;
+  rows_swap16(a, b);
+  a += b; b = a;
+  rows_swap32(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float rows_max(float v) {
+  float a = v, b = v;
+  rows_swap16(a, b);
+  a = fmaxf(a, b); b = a;
+  rows_swap32(a, b);
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -99,9 +124,10 @@ __host__ __device__ __forceinline__ int wswz(int rho) { return 3 * ((rho >> 2) &
 
 // ---- weight pre-packing: reference-layout fp16 matrices -> the kernel's tile stream --------------------------------
 // One thread per 16-B chunk of the stream.  Tile t of a matrix W[N][ldw] (k columns 32t .. 32t+31, offset kofs):
-//   image byte  half*HB + rho*64 + pc*16  <-  W[n(half, rho)][kofs + 32t + 8*(pc ^ wswz(rho)) .. +8]
-// with n(half, rho) = half*NH + (ii>>2)*(NH/4) + fn*4 + (ii&3), fn = rho>>4, ii = rho&15 (NH = rows per half): output
-// lane (g, r) of fragment b then owns column half*NH + g*(NH/4) + b*4 + r - NH/4 consecutive columns per lane.
+//   image byte  quarter*QB + rho*64 + pc*16  <-  W[n(quarter, rho)][kofs + 32t + 8*(pc ^ wswz(rho)) .. +8]
+// with n(quarter, rho) = quarter*NQ + (ii>>2)*(NQ/4) + fn*4 + (ii&3), fn = rho>>4, ii = rho&15 (NQ = rows per quarter = the
+// columns of one wave: 80, or 64 for a GEGLU-1 tile): output lane (g, r) of fragment b then owns column
+// quarter*NQ + g*(NQ/4) + b*4 + r - NQ/4 consecutive columns per lane.
 struct PackSrc { const half_t* w; int ldw; };
 __global__ void k_attn_tail_pack(PackSrc so, PackSrc q, PackSrc co, PackSrc w1, PackSrc w2, PackSrc wo, half_t* dst) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;  // 16-B chunk index in the stream
@@ -110,21 +136,21 @@ __global__ void k_attn_tail_pack(PackSrc so, PackSrc q, PackSrc co, PackSrc w1, 
   const half_t* W; int ldw, row0 = 0, kofs = 0, NH, t;
   if (byte < SEG0_BYTES) {
     const int ti = byte / TILE_FULL; byte -= ti * TILE_FULL;
-    W = ti < 10 ? so.w : q.w; ldw = ti < 10 ? so.ldw : q.ldw; t = ti % 10; NH = 160;
+    W = ti < 10 ? so.w : q.w; ldw = ti < 10 ? so.ldw : q.ldw; t = ti % 10; NH = 80;
   } else {
     byte -= SEG0_BYTES;
-    if (byte < 10 * TILE_FULL) { t = byte / TILE_FULL; byte -= t * TILE_FULL; W = co.w; ldw = co.ldw; NH = 160; }
+    if (byte < 10 * TILE_FULL) { t = byte / TILE_FULL; byte -= t * TILE_FULL; W = co.w; ldw = co.ldw; NH = 80; }
     else if (byte < 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES) {
       byte -= 10 * TILE_FULL;
       const int jc = byte / FFN_CHUNK_BYTES; byte -= jc * FFN_CHUNK_BYTES;
-      if (byte < 10 * TILE_G1) { t = byte / TILE_G1; byte -= t * TILE_G1; W = w1.w; ldw = w1.ldw; row0 = jc * 256; NH = 128; }
-      else { byte -= 10 * TILE_G1; t = byte / TILE_FULL; byte -= t * TILE_FULL; W = w2.w; ldw = w2.ldw; kofs = jc * 128; NH = 160; }
+      if (byte < 10 * TILE_G1) { t = byte / TILE_G1; byte -= t * TILE_G1; W = w1.w; ldw = w1.ldw; row0 = jc * 256; NH = 64; }
+      else { byte -= 10 * TILE_G1; t = byte / TILE_FULL; byte -= t * TILE_FULL; W = w2.w; ldw = w2.ldw; kofs = jc * 128; NH = 80; }
     } else {
       byte -= 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES;
-      t = byte / TILE_FULL; byte -= t * TILE_FULL; W = wo.w; ldw = wo.ldw; NH = 160;
+      t = byte / TILE_FULL; byte -= t * TILE_FULL; W = wo.w; ldw = wo.ldw; NH = 80;
     }
   }
-  const int half = byte / (NH * 64), rb = byte - half * NH * 64;
+  const int half = byte / (NH * 64), rb = byte - half * NH * 64;  // "half" = quarter (0..3), NH = its rows
   const int rho = rb >> 6, pc = (rb >> 4) & 3;
   const int fn = rho >> 4, ii = rho & 15;
   const int n = row0 + half * NH + (ii >> 2) * (NH / 4) + fn * 4 + (ii & 3);
@@ -133,7 +159,7 @@ __global__ void k_attn_tail_pack(PackSrc so, PackSrc q, PackSrc co, PackSrc w1, 
 }
 
 // head stream: conv_in, then the q / k / v row blocks of in_proj (rows 0..319 / 320..639 / 640..959), all K = 320.
-// The v tiles keep the IDENTITY row order (LDS row rho of half h = weight row h*160 + rho): that stage runs with swapped
+// The v tiles keep the IDENTITY row order (LDS row rho of quarter h = weight row h*80 + rho): that stage runs with swapped
 // MFMA operands and wants consecutive channels across a fragment's 16 lanes.
 __global__ void k_attn_head_pack(PackSrc cin, PackSrc inproj, half_t* dst) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,9 +169,9 @@ __global__ void k_attn_head_pack(PackSrc cin, PackSrc inproj, half_t* dst) {
   const int mat = ti / 10, t = ti - mat * 10;
   const half_t* W = mat == 0 ? cin.w : inproj.w;
   const int ldw = mat == 0 ? cin.ldw : inproj.ldw, row0 = mat == 0 ? 0 : (mat - 1) * 320;
-  const int half = byte / 10240, rb = byte - half * 10240;
+  const int half = byte / 5120, rb = byte - half * 5120;  // quarter 0..3: 80 rows of 64 B
   const int rho = rb >> 6, pc = (rb >> 4) & 3, fn = rho >> 4, ii = rho & 15;
-  const int n = row0 + half * 160 + (mat == 3 ? rho : (ii >> 2) * 40 + fn * 4 + (ii & 3));
+  const int n = row0 + half * 80 + (mat == 3 ? rho : (ii >> 2) * 20 + fn * 4 + (ii & 3));
   const int k = 32 * t + 8 * (pc ^ wswz(rho));
   *(h8*)(dst + (size_t)ci * 8) = *(const h8*)(W + (size_t)n * ldw + k);
 }
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wn = wave;  // 1(M) x 4(N) wave grid: every wave owns all 64 rows and 80 of the 320 columns (FM = 4, FN = 5)
   const int rsel = lane & 15, key = lane & 7, g = lane >> 4;
   const int lrow = lane >> 3, cch = (lane & 7) ^ lrow;  // gather DMA: LDS row within an 8-row piece, logical 16-B chunk fetched
   const int m0 = blockIdx.x * BM;
@@ -178,7 +204,6 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     if (seg == 0) { live = gi < SEG0_TILES; return gi * TILE_FULL; }
     if (gi < 10) return SEG0_BYTES + gi * TILE_FULL;
     if (gi < 150) {
-#if TSD_CHAIN_PIPE
       // visiting order W1(0) | W1(1) W2(0) | W1(2) W2(1) | ... | W1(9) W2(8) | W2(9): chunk j's activation is computed under the
       // MFMAs of chunk j-1's second GEMM (the packed image keeps its [W1(j), W2(j)] layout - only the walk changes)
       const int q = gi - 10;
@@ -189,12 +214,6 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       const int base = SEG0_BYTES + 10 * TILE_FULL + jc * FFN_CHUNK_BYTES;
       if (!second) { g1 = true; return base + r * TILE_G1; }
       return base + 10 * TILE_G1 + r * TILE_FULL;
-#else
-      const int q = gi - 10, jc = q / 14, r = q - 14 * jc;
-      const int base = SEG0_BYTES + 10 * TILE_FULL + jc * FFN_CHUNK_BYTES;
-      if (r < 10) { g1 = true; return base + r * TILE_G1; }
-      return base + 10 * TILE_G1 + (r - 10) * TILE_FULL;
-#endif
     }
     live = gi < SEG1_TILES;
     return SEG0_BYTES + 10 * TILE_FULL + 10 * FFN_CHUNK_BYTES + (gi - 150) * TILE_FULL;
@@ -226,40 +245,41 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     }
   };
 
-  // ---- one GEMM stage: acc[2][FN] (+)= Atile[64][nk*32] . W^T over the next nk tiles of the stream -----------------
+  // ---- one GEMM stage: acc[4][5] (+)= Atile[64][nk*32] . W^T over the next nk tiles of the stream ------------------
   // EXTRA = VMEM loads the caller issued since the last DMA piece (bias / residual prefetch): they are younger than the
   // tiles the first wait is for.
-  const int a_rd = (wm * 32 + rsel) * 128;
+  // Wave tile 64 x 80 (round 4; rounds 2-3 ran 2 x 2 waves of 32 x 160): 4 + 5 fragment reads per 20 MFMAs instead of 2 + 10 -
+  // a tile step costs its MFMAs plus its fragment reads, added up (DESIGN.md 4.1 "what a K tile costs").
+  const int a_rd = rsel * 128;
   const int w_rd = rsel * 64 + ((g ^ wswz(rsel)) << 4);
-  auto gemm = [&](auto fn_c, auto seg_c, auto zero_c, auto extra_c, f4 (&acc)[2][10], int a_base, int nk, auto swap_c) {
-    constexpr int FN = decltype(fn_c)::value, SEG = decltype(seg_c)::value, EXTRA = decltype(extra_c)::value;
+  auto gemm = [&](auto seg_c, auto zero_c, auto extra_c, f4 (&acc)[4][5], int a_base, int nk, auto swap_c) {
+    constexpr int FN = 5, SEG = decltype(seg_c)::value, EXTRA = decltype(extra_c)::value;
     constexpr bool ZERO = decltype(zero_c)::value;
     // SWAP: D = Afrag x Wfrag^T instead of Wfrag x Afrag^T - a lane then holds ONE weight row (= lane & 15 of fragment b)
     // and FOUR consecutive token rows (4g + r of fragment a): the transposed output the V^T projection needs
     constexpr bool SWAP = decltype(swap_c)::value;
     if (ZERO) {
 #pragma unroll
-      for (int a = 0; a < 2; a++)
+      for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < FN; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
     }
     // Software pipeline over the tiles (one wave per SIMD: nobody else hides the LDS latency): the fragment reads of
     // tile t are issued right after its barrier and land while the MFMAs of tile t-1 run from the other register set.
-    h8 afA[2], wfA[FN], afB[2], wfB[FN];
-    // One pipeline step = barrier of tile gt, then the 2*FN MFMAs of tile gt-1 (register set p*) with the 2 + FN fragment
-    // reads of tile gt (into set n*) and the wave's DMA instructions for tile gt+4 spread between them: a burst of 48
-    // ds_read_b128 from the four waves right after the barrier would hold the LDS (and every wave's issue) for ~200 cycles.
-    auto step = [&](int kt, h8 (&af)[2], h8 (&wf)[FN], const h8 (&paf)[2], const h8 (&pwf)[FN], bool have_prev, bool have_next) {
+    h8 afA[4], wfA[FN], afB[4], wfB[FN];
+    // One pipeline step = barrier of tile gt, then the 4*FN MFMAs of tile gt-1 (register set p*) with the 4 + FN fragment
+    // reads of tile gt (into set n*) and the wave's DMA instructions for tile gt+4 spread between them.
+    auto step = [&](int kt, h8 (&af)[4], h8 (&wf)[FN], const h8 (&paf)[4], const h8 (&pwf)[FN], bool have_prev, bool have_next) {
       bool g1 = false, live = false;
       int off = 0, s4 = 0;
       const char *sA = smem, *sW = smem;
       if (have_next) {
         // tile gt has landed: the three younger tiles (and the caller's EXTRA loads, which sit between tile gt+3 and tile
         // gt+4 of the stage's first tile in the queue) may stay in flight
-        int younger = EXTRA > 0 && kt < 4 ? EXTRA : 0;
+        int younger = 0;
 #pragma unroll
         for (int d = 1; d <= 3; d++) { bool yg1, ylive; tile_off(SEG, gt + d, yg1, ylive); younger += yg1 ? 4 : 5; }
-        switch (younger - (EXTRA > 0 && kt < 4 ? EXTRA : 0)) {
+        switch (younger) {
           case 12: if (EXTRA > 0 && kt < 4) wait_vm<12 + EXTRA>(); else wait_vm<12>(); break;
           case 13: if (EXTRA > 0 && kt < 4) wait_vm<13 + EXTRA>(); else wait_vm<13>(); break;
           case 14: if (EXTRA > 0 && kt < 4) wait_vm<14 + EXTRA>(); else wait_vm<14>(); break;
@@ -269,33 +289,32 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         sA = smem + a_base + (kt >> 1) * A_KT + a_rd + ((((kt & 1) * 4 + g) ^ key) << 4);
-        sW = smem + RING_OFF + sl * SLOT + wn * (FN == 10 ? 10240 : 8192) + w_rd;
+        sW = smem + RING_OFF + sl * SLOT + wn * 5120 + w_rd;
         off = tile_off(SEG, gt + 4, g1, live);
         s4 = sl == 0 ? 4 : sl - 1;  // (sl + 4) % 5: the slot tile gt-1 just left
       }
-      constexpr int NM = 2 * FN, NR = 2 + FN;
+      constexpr int NM = 4 * FN, NR = 4 + FN;
       if (!have_prev) {  // first tile of the stage: nothing to multiply yet
 #pragma unroll
-        for (int a = 0; a < 2; a++) af[a] = *(const h8*)(sA + a * 2048);
+        for (int a = 0; a < 4; a++) af[a] = *(const h8*)(sA + a * 2048);
 #pragma unroll
         for (int b = 0; b < FN; b++) wf[b] = *(const h8*)(sW + b * 1024);
 #pragma unroll
         for (int i = 0; i < 5; i++) if (!(g1 && i == 4)) piece(off, g1, live, s4, i);
       } else {
-        int ri = 0, pi = 0;
 #pragma unroll
         for (int q = 0; q < NM; q++) {
-          const int b = q >> 1, a = q & 1;
+          const int b = q >> 2, a = q & 3;
           if (SWAP) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(paf[a], pwf[b], acc[a][b], 0, 0, 0);
           else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], acc[a][b], 0, 0, 0);
           if (have_next) {
             __builtin_amdgcn_sched_barrier(0);
             // reads: one after each of the first NR MFMAs ... (A fragments first: every MFMA of the next step needs one)
             if (q < NR) {
-              if (q < 2) af[q] = *(const h8*)(sA + q * 2048);
-              else wf[q - 2] = *(const h8*)(sW + (q - 2) * 1024);
+              if (q < 4) af[q] = *(const h8*)(sA + q * 2048);
+              else wf[q - 4] = *(const h8*)(sW + (q - 4) * 1024);
             }
-            // ... DMA: one after every third / fourth MFMA
+            // ... DMA: one after every fourth MFMA
             if ((q + 1) % (NM / 5) == 0 && (q + 1) / (NM / 5) - 1 < 5) {
               const int i = (q + 1) / (NM / 5) - 1;
               if (!(g1 && i == 4)) piece(off, g1, live, s4, i);
@@ -315,150 +334,147 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     }
     step(nk, afA, wfA, afB, wfB, true, false);
   };
-  using I8 = std::integral_constant<int, 8>;
-  using I10 = std::integral_constant<int, 10>;
-  using I20 = std::integral_constant<int, 20>;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I25 = std::integral_constant<int, 25>;
   using Yes = std::true_type;
   using No = std::false_type;
 
   // ---- accumulator-layout helpers: lane (rsel, g) of fragment row a holds columns cbase + b*4 + r ------------------
-  const int cbase = wn * 160 + g * 40;
-  auto load_cols = [&](const float* vec, f4 (&bv)[10]) {
+  const int cbase = wn * 80 + g * 20;
+  auto load_cols = [&](const float* vec, f4 (&bv)[5]) {
 #pragma unroll
-    for (int b = 0; b < 10; b++) bv[b] = *(const f4*)(vec + cbase + b * 4);
+    for (int b = 0; b < 5; b++) bv[b] = *(const f4*)(vec + cbase + b * 4);
   };
-  // fp16 rows (residual sources): 40 consecutive columns = five 16-B loads per fragment row
-  auto load_rows_raw = [&](const half_t* src, int ld, h8 (&raw)[2][5]) {
+  // fp16 rows (residual sources): 20 consecutive columns = five 8-B loads per fragment row
+  auto load_rows_raw = [&](const half_t* src, int ld, h4 (&raw)[4][5]) {
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const half_t* rp = src + (long long)(m0 + wm * 32 + a * 16 + rsel) * ld + cbase;
+    for (int a = 0; a < 4; a++) {
+      const half_t* rp = src + (long long)(m0 + a * 16 + rsel) * ld + cbase;
 #pragma unroll
-      for (int q = 0; q < 5; q++) raw[a][q] = *(const h8*)(rp + q * 8);
+      for (int b = 0; b < 5; b++) raw[a][b] = *(const h4*)(rp + b * 4);
     }
   };
-  // write fp16((v - sub) * mul) into the A tile (swizzled A-operand layout): global 16-B chunk index = wn*20 + g*5 + q
-  auto store_a_tile = [&](const f4 (&v)[2][10], float mul0, float sub0, float mul1, float sub1) {
+  // LDS byte offset, inside a swizzled [k-tile][64 rows][128 B] A-operand tile, of the 8-B piece holding columns col .. col+3 of `row`
+  auto a_piece = [&](int row, int col) { return (col >> 6) * A_KT + row * 128 + ((((col >> 3) & 7) ^ (row & 7)) << 4) + (col & 4) * 2; };
+  // write fp16((v - sub) * mul) into the A tile (swizzled A-operand layout)
+  auto store_a_tile = [&](const f4 (&v)[4][5], const float (&mul)[4], const float (&sub)[4]) {
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const int row = wm * 32 + a * 16 + rsel;
-      const float mul = a ? mul1 : mul0, sub = a ? sub1 : sub0;
+    for (int a = 0; a < 4; a++) {
+      const int row = a * 16 + rsel;
 #pragma unroll
-      for (int q = 0; q < 5; q++) {
-        h8 o;
+      for (int b = 0; b < 5; b++) {
+        h4 o;
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = (half_t)((v[a][2 * q + (j >> 2)][j & 3] - sub) * mul);
-        const int cg = wn * 20 + g * 5 + q;
-        *(h8*)(smem + A_OFF + (cg >> 3) * A_KT + row * 128 + (((cg & 7) ^ key) << 4)) = o;
+        for (int r = 0; r < 4; r++) o[r] = (half_t)((v[a][b][r] - sub[a]) * mul[a]);
+        *(h4*)(smem + A_OFF + a_piece(row, cbase + b * 4)) = o;
       }
     }
   };
   // LayerNorm of the residual stream into the A tile: (x - mean) / (sigma + eps), population sigma, no affine
   // (helpers/utils.mojo:2052-2061 via :1845-1885; App.A D8).  Each column wave computes the exact two-pass mean / M2
-  // of its 160 columns; the two are merged after ONE exchange (Chan et al.).
+  // of its 80 columns; the four are merged after ONE exchange (Chan et al., equal counts).
   float* scr = (float*)(smem + SCR_OFF);
-  auto layernorm_to_a = [&](const f4 (&v)[2][10]) {
-    float mw[2], m2w[2];
+  auto layernorm_to_a = [&](const f4 (&v)[4][5]) {
+    float mw[4], m2w[4];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
+    for (int a = 0; a < 4; a++) {
       float t = 0.f;
 #pragma unroll
-      for (int b = 0; b < 10; b++) t += (v[a][b][0] + v[a][b][1]) + (v[a][b][2] + v[a][b][3]);
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);
-      mw[a] = t * (1.f / 160.f);
+      for (int b = 0; b < 5; b++) t += (v[a][b][0] + v[a][b][1]) + (v[a][b][2] + v[a][b][3]);
+      t = rows_sum(t);
+      mw[a] = t * (1.f / 80.f);
       float u = 0.f;
 #pragma unroll
-      for (int b = 0; b < 10; b++)
+      for (int b = 0; b < 5; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) { const float d = v[a][b][r] - mw[a]; u += d * d; }
-      u += __shfl_xor(u, 16);
-      u += __shfl_xor(u, 32);
+      u = rows_sum(u);
       m2w[a] = u;
-      if (g == 0) *(f2*)(scr + ((wm * 32 + a * 16 + rsel) * 2 + wn) * 2) = f2{mw[a], u};
+      if (g == 0) *(f2*)(scr + ((a * 16 + rsel) * 4 + wn) * 2) = f2{mw[a], u};
     }
     lds_barrier();  // also: every wave is past its last read of the old A tile
-    float mean[2], rs[2];
+    float mean[4], rs[4];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const f2 o = *(const f2*)(scr + ((wm * 32 + a * 16 + rsel) * 2 + (wn ^ 1)) * 2);
-      const float dm = mw[a] - o[0];
-      mean[a] = 0.5f * (mw[a] + o[0]);
-      const float m2 = m2w[a] + o[1] + dm * dm * 80.f;
+    for (int a = 0; a < 4; a++) {
+      const f4 p01 = *(const f4*)(scr + (a * 16 + rsel) * 8), p23 = *(const f4*)(scr + (a * 16 + rsel) * 8 + 4);
+      const float mu = 0.25f * ((p01[0] + p01[2]) + (p23[0] + p23[2]));
+      const float d0 = p01[0] - mu, d1 = p01[2] - mu, d2 = p23[0] - mu, d3 = p23[2] - mu;
+      const float m2 = ((p01[1] + p01[3]) + (p23[1] + p23[3])) + 80.f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      mean[a] = mu;
       rs[a] = 1.f / (sqrtf(m2 * (1.f / C)) + p.eps);
     }
-    store_a_tile(v, rs[0], mean[0], rs[1], mean[1]);
+    store_a_tile(v, rs, mean);
   };
+  const float one4[4] = {1.f, 1.f, 1.f, 1.f}, zero4[4] = {0.f, 0.f, 0.f, 0.f};
 
   if constexpr (KIND == KIND_HEAD) {
     // =============================================================================================================
     // head of the block (diffusion.mojo:116-124): GroupNorm-apply -> conv_in (1x1) -> tok ; LayerNorm -> q, k, V^T
-    f4 T[2][10], acc[2][10], accq[2][10], bv[10];
-    h8 raw[2][5];
+    f4 T[4][5], acc[4][5], accq[4][5], bv[5];
+    h4 raw[4][5];
     load_rows_raw(p.x, p.ld_x, raw);
-    f2 gst[4];  // (mean, 1/(sigma+eps)) of this lane's four groups of 10 channels
+    f2 gst[2];  // (mean, 1/(sigma+eps)) of this lane's two groups of 10 channels
 #pragma unroll
-    for (int k = 0; k < 4; k++) gst[k] = *(const f2*)(p.gn_stats + ((long long)bsmp * 32 + wn * 16 + g * 4 + k) * 2);
+    for (int k = 0; k < 2; k++) gst[k] = *(const f2*)(p.gn_stats + ((long long)bsmp * 32 + wn * 8 + g * 2 + k) * 2);
     load_cols(p.b_in, bv);
     seg_begin(0);
     // GroupNorm (32 groups, eps 1e-6, no SiLU; helpers/utils.mojo:1845-1885) of the x tile -> A tile
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const int row = wm * 32 + a * 16 + rsel;
+    for (int a = 0; a < 4; a++) {
+      const int row = a * 16 + rsel;
 #pragma unroll
-      for (int q = 0; q < 5; q++) {
-        h8 o;
+      for (int b = 0; b < 5; b++) {
+        h4 o;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int grp = (q * 8 + j) / 10;
-          o[j] = (half_t)(((float)raw[a][q][j] - gst[grp][0]) * gst[grp][1]);
+        for (int r = 0; r < 4; r++) {
+          const int grp = (b * 4 + r) / 10;
+          o[r] = (half_t)(((float)raw[a][b][r] - gst[grp][0]) * gst[grp][1]);
         }
-        const int cg = wn * 20 + g * 5 + q;
-        *(h8*)(smem + A_OFF + (cg >> 3) * A_KT + row * 128 + (((cg & 7) ^ key) << 4)) = o;
+        *(h4*)(smem + A_OFF + a_piece(row, cbase + b * 4)) = o;
       }
     }
     CTS(1);
     // ---- tok = GN(x) . Wc^T + b  (diffusion.mojo:117) ; the first tile barrier publishes the A tile -----------------------
     // No global store happens before the last GEMM is done: stores share vmcnt with the DMA stream, and draining them
     // (an HBM write round trip) in the middle of the kernel costs more than any stage.  tok / q / k wait in registers.
-    gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
-    h8 tokh[2][5];
+    gemm(I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+    h4 tokh[4][5];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
+    for (int a = 0; a < 4; a++) {
 #pragma unroll
-      for (int b = 0; b < 10; b++) T[a][b] = acc[a][b] + bv[b];
+      for (int b = 0; b < 5; b++) {
+        T[a][b] = acc[a][b] + bv[b];
 #pragma unroll
-      for (int q = 0; q < 5; q++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) tokh[a][q][j] = (half_t)T[a][2 * q + (j >> 2)][j & 3];
+        for (int r = 0; r < 4; r++) tokh[a][b][r] = (half_t)T[a][b][r];
+      }
     }
     CTS(2);
     layernorm_to_a(T);   // the LayerNorm sees the fp32 tok (the unfused graph normalises its fp16 rounding)
     CTS(3);
     // ---- q, k = LN(tok) . W^T  (helpers/attention.mojo:29, in_bias = False) -----------------------------------------------
-    f4 acck[2][10];
-    gemm(I10{}, I0{}, Yes{}, I0{}, accq, A_OFF, 10, No{});
-    gemm(I10{}, I0{}, Yes{}, I0{}, acck, A_OFF, 10, No{});
+    f4 acck[4][5];
+    gemm(I0{}, Yes{}, I0{}, accq, A_OFF, 10, No{});
+    gemm(I0{}, Yes{}, I0{}, acck, A_OFF, 10, No{});
     CTS(4);
     CTS(5);
-    // ---- V^T = Wv . LN(tok)^T : swapped operands, lane (channel wn*160 + b*16 + rsel) holds tokens wm*32 + a*16 + 4g + r ----
-    gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, Yes{});
+    // ---- V^T = Wv . LN(tok)^T : swapped operands, lane (channel wn*80 + b*16 + rsel) holds tokens a*16 + 4g + r ----
+    gemm(I0{}, Yes{}, I0{}, acc, A_OFF, 10, Yes{});
     CTS(6);
     wait_vm<0>();   // the dead tail DMAs (zero-size descriptors still WRITE zeros) have landed: the ring is really free
     lds_barrier();  // every wave is done with the A tile and the ring: both become output staging
     // Outputs leave through LDS so that every global store instruction writes whole contiguous row segments (lane-owned
-    // 80-B row pieces stored directly are 64 scattered 16-B writes per instruction: store-issue bound).
+    // 40-B row pieces stored directly are 64 scattered 8-B writes per instruction: store-issue bound).
     //   A tile region : V^T [320 channels][64 tokens] (128-B rows, 16-B chunks XOR-swizzled by channel & 7)
-    //   ring region   : two row-major [64 rows][640 B] tiles at a 656-B pitch (conflict-free 16-B writes)
+    //   ring region   : two row-major [64 rows][640 B] tiles at a 656-B pitch
     constexpr int RP = 656, ST0 = RING_OFF, ST1 = RING_OFF + 64 * RP;
     static_assert(ST1 + 64 * RP <= SCR_OFF, "staging tiles must fit in the ring region");
-    // stage fragment rows: this lane's 8 columns cbase + 8q .. of fragment row a
+    // stage fragment rows: this lane's 4 columns cbase + 4b .. of fragment row a
 #define STAGE_ROWS_ACC(base, v)                                                                                         \
-  _Pragma("unroll") for (int a = 0; a < 2; a++) _Pragma("unroll") for (int q = 0; q < 5; q++) {                          \
-    h8 o_;                                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < 8; j++) o_[j] = (half_t)v[a][2 * q + (j >> 2)][j & 3];                         \
-    *(h8*)(smem + (base) + (wm * 32 + a * 16 + rsel) * RP + (cbase + q * 8) * 2) = o_;                                   \
+  _Pragma("unroll") for (int a = 0; a < 4; a++) _Pragma("unroll") for (int b = 0; b < 5; b++) {                          \
+    h4 o_;                                                                                                              \
+    _Pragma("unroll") for (int r = 0; r < 4; r++) o_[r] = (half_t)v[a][b][r];                                            \
+    *(h4*)(smem + (base) + (a * 16 + rsel) * RP + (cbase + b * 4) * 2) = o_;                                             \
   }
     auto flush_rows = [&](int base, half_t* dst, int ld) {  // 2560 16-B chunks, 40 per row: a wave stores 1 KiB = 1.6 full rows
 #pragma unroll
@@ -468,16 +484,16 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       }
     };
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int q = 0; q < 5; q++) *(h8*)(smem + ST0 + (wm * 32 + a * 16 + rsel) * RP + (cbase + q * 8) * 2) = tokh[a][q];
+      for (int b = 0; b < 5; b++) *(h4*)(smem + ST0 + (a * 16 + rsel) * RP + (cbase + b * 4) * 2) = tokh[a][b];
     STAGE_ROWS_ACC(ST1, accq)
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int b = 0; b < 10; b++) {
-        const int c = wn * 160 + b * 16 + rsel;
-        const int tkn = wm * 32 + a * 16 + 4 * g;  // first of this lane's four tokens
+      for (int b = 0; b < 5; b++) {
+        const int c = wn * 80 + b * 16 + rsel;
+        const int tkn = a * 16 + 4 * g;  // first of this lane's four tokens
         h4 o;
 #pragma unroll
         for (int r = 0; r < 4; r++) o[r] = (half_t)acc[a][b][r];
@@ -503,10 +519,10 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     CTS(7); CTS(8);
   } else {
   // =================================================================================================================
-  f4 T[2][10];    // residual stream (fp32)
-  f4 acc[2][10];  // stage accumulators
-  f4 bv[10];      // per-column epilogue vector of the current stage (prefetched under the stage's GEMM)
-  h8 raw[2][5];   // residual rows in flight (tok, later x)
+  f4 T[4][5];     // residual stream (fp32)
+  f4 acc[4][5];   // stage accumulators
+  f4 bv[5];       // per-column epilogue vector of the current stage (prefetched under the stage's GEMM)
+  h4 raw[4][5];   // residual rows in flight (tok, later x)
   // ---- prologue: ao tile -> A tile ; residual 1 and the first bias in flight ; four weight tiles ahead ---------------
   {
     const rsrc_t ra = make_rsrc(p.ao);
@@ -521,21 +537,18 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   seg_begin(0);
   CTS(1);
   // ---- tok2 = ao . Wso^T + b + tok ------------------------------------------------------------------------------------
-  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+  gemm(I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int q = 0; q < 5; q++)
+    for (int b = 0; b < 5; b++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int b = 2 * q + (j >> 2), r = j & 3;
-        T[a][b][r] = (float)raw[a][q][j] + (acc[a][b][r] + bv[b][r]);
-      }
+      for (int r = 0; r < 4; r++) T[a][b][r] = (float)raw[a][b][r] + (acc[a][b][r] + bv[b][r]);
   CTS(2);
   layernorm_to_a(T);
   CTS(3);
   // ---- q = LN(tok2) . Wq^T  (scaled by softmax scale * log2 e) -----------------------------------------------------------
-  gemm(I10{}, I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+  gemm(I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
   CTS(4);
   wait_vm<0>();   // the dead tail of segment 0 has landed: the ring region is free for the context keys / values
   lds_barrier();  // every wave is done reading LN(tok2) and the last weight tile
@@ -566,17 +579,20 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       }
     }
   }
-  store_a_tile(acc, p.qscale, 0.f, p.qscale, 0.f);  // q -> A tile while the context tiles fly
+  {
+    const float qs4[4] = {p.qscale, p.qscale, p.qscale, p.qscale};
+    store_a_tile(acc, qs4, zero4);  // q -> A tile while the context tiles fly
+  }
   load_cols(p.bco, bv);
-  wait_vm<10>();  // the context tiles have landed (the 10 bias loads are younger)
+  wait_vm<5>();   // the context tiles have landed (the 5 bias loads are younger)
   lds_barrier();  // q tile and context tiles visible
-  // per wave: rows wm*32.., heads 4*wn .. 4*wn+3
+  // per wave: all 64 rows, heads 2*wn and 2*wn+1 (its own 80 columns of q: no other wave reads or writes them)
 #pragma unroll
-  for (int hh = 0; hh < 4; hh++) {
-    const int h = wn * 4 + hh, c0 = h * 5;  // first 16-B chunk of the head's 40 columns
-    f4 sc[2][5];
+  for (int hh = 0; hh < 2; hh++) {
+    const int h = wn * 2 + hh, c0 = h * 5;  // first 16-B chunk of the head's 40 columns
+    f4 sc[4][5];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
       for (int b = 0; b < 5; b++) sc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -584,24 +600,24 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       // k-step 0: chunks c0 .. c0+3 ; k-step 1: chunk c0+4 in lane group 0, zeros in the key operand elsewhere
       const int cg = st == 0 ? c0 + g : c0 + 4;
       const int ktile = cg >> 3, cpos = cg & 7;
-      h8 qa[2], kb[5];
+      h8 qa[4], kb[5];
 #pragma unroll
-      for (int a = 0; a < 2; a++) qa[a] = *(const h8*)(smem + A_OFF + ktile * A_KT + a_rd + a * 2048 + ((cpos ^ key) << 4));
+      for (int a = 0; a < 4; a++) qa[a] = *(const h8*)(smem + A_OFF + ktile * A_KT + a_rd + a * 2048 + ((cpos ^ key) << 4));
 #pragma unroll
       for (int b = 0; b < 5; b++) {
         kb[b] = *(const h8*)(smem + RING_OFF + ktile * KT_B + (b * 16 + rsel) * 128 + ((cpos ^ key) << 4));
         if (st == 1 && g != 0) kb[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
       }
 #pragma unroll
-      for (int a = 0; a < 2; a++)
+      for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 5; b++) sc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb[b], qa[a], sc[a][b], 0, 0, 0);
     }
     // softmax over the keys of each query row: 20 in-lane scores x 4 lane groups (max subtraction, App.A D6)
-    h8 pf[2][3];
-    float rinv[2];
+    h8 pf[4][3];
+    float rinv[4];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
+    for (int a = 0; a < 4; a++) {
       float mx = -1.0e30f;
 #pragma unroll
       for (int b = 0; b < 5; b++)
@@ -611,8 +627,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
           if (kidx >= p.T) sc[a][b][r] = -1.0e30f;
           mx = fmaxf(mx, sc[a][b][r]);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = rows_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) {
@@ -626,14 +641,13 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         }
         pf[a][kk] = o;
       }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
+      sum = rows_sum(sum);
       rinv[a] = 1.f / sum;
     }
     // O_h = P . V_h : channel rows h*40 + b*16 + rsel of the V^T tiles (rows past the head's 40 give discarded outputs)
-    f4 oc[2][3];
+    f4 oc[4][3];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
       for (int b = 0; b < 3; b++) oc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -649,25 +663,24 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         }
       }
 #pragma unroll
-      for (int a = 0; a < 2; a++)
+      for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) oc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[b], pf[a][kk], oc[a][b], 0, 0, 0);
     }
-    // The head's output overwrites the head's q columns in the A tile.  Columns h*40 .. h*40+39 of rows wm*32 .. +31 are
-    // read (as q) by THIS wave only - heads 4wn .. 4wn+3 belong to the column wave, the rows to the row wave - and its
-    // QK^T for this head is done, so no barrier is needed.  lane (g, r) of fragment b holds channel h*40 + b*16 + 4g + r.
+    // The head's output overwrites the head's q columns in the A tile.  Columns h*40 .. h*40+39 are read (as q) and written by
+    // THIS wave only, and its QK^T for this head is done, so no barrier is needed.  lane (g, r) of fragment b holds channel
+    // h*40 + b*16 + 4g + r.
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const int row = wm * 32 + a * 16 + rsel;
+    for (int a = 0; a < 4; a++) {
+      const int row = a * 16 + rsel;
 #pragma unroll
       for (int b = 0; b < 3; b++) {
         const int d = b * 16 + 4 * g;
         if (d < 40) {
-          const int col = h * 40 + d;
           h4 o;
 #pragma unroll
           for (int r = 0; r < 4; r++) o[r] = (half_t)(oc[a][b][r] * rinv[a]);
-          *(h4*)(smem + A_OFF + (col >> 6) * A_KT + row * 128 + ((((col >> 3) & 7) ^ key) << 4) + (col & 7) * 2) = o;
+          *(h4*)(smem + A_OFF + a_piece(row, h * 40 + d)) = o;
         }
       }
     }
@@ -676,123 +689,130 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   CTS(5);
   seg_begin(1);
   // ---- tok3 = attn . Wco^T + b + tok2 -------------------------------------------------------------------------------
-  gemm(I10{}, I1{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+  gemm(I1{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 10; b++) T[a][b] += acc[a][b] + bv[b];
+    for (int b = 0; b < 5; b++) T[a][b] += acc[a][b] + bv[b];
   layernorm_to_a(T);
   CTS(6);
   // ---- GEGLU feed-forward: ten chunks of 128 hidden units; the second GEMM accumulates over the chunks ------------------
-  f4 acc2[2][10];
+  f4 acc2[4][5];
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 10; b++) acc2[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-#if TSD_CHAIN_PIPE
+    for (int b = 0; b < 5; b++) acc2[a][b] = f4{0.f, 0.f, 0.f, 0.f};
   {
     // ONE software pipeline over the 140 GEGLU tiles (round 3).  Round 2 ran per chunk GEMM-1 (10 tiles) -> a * gelu(g) ->
-    // GEMM-2 (4 tiles) as three serial phases: every GEMM call opened with a read-only step and closed with an MFMA-only step,
-    // and the 32 activations per lane ran with the matrix pipe idle - 9.8 K ticks per chunk for 3.8 K of MFMA.
-    // Here a step = barrier of tile gt, the MFMAs of tile gt-1 (whatever GEMM it belongs to) from one fragment register set,
-    // the fragment reads of tile gt into the other, the DMA of tile gt+4 - straight through the walk
+    // GEMM-2 (4 tiles) as three serial phases.  Here a step = barrier of tile gt, the MFMAs of tile gt-1 (whatever GEMM it belongs
+    // to) from one fragment register set, the fragment reads of tile gt into the other, the DMA of tile gt+4 - straight through the walk
     //   G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(9) G2(8) | G2(9)
-    // and chunk j's activation is computed 8 values per step under the 20 MFMAs of G2(j-1)'s tiles (the accumulator of G1(j)
-    // is complete by then and G1(j+1) has not started), kept in 16 registers, and written to the activation tile at the second
-    // step of G1(j+1) - two barriers after G2(j-1)'s last read of that tile, nine steps before G2(j)'s first.  Same products
-    // in the same order as round 2: bit-identical results.
-    f4 b1v[8];
-    h8 oreg[2][2];
-    h8 afS[2][2], wfS[2][10];
+    // and chunk j's activation is computed under the MFMAs of G2(j-1)'s tiles (the accumulator of G1(j) is complete by then and
+    // G1(j+1) has not started), kept in 16 registers, and written to the activation tile at the second step of G1(j+1) - two
+    // barriers after G2(j-1)'s last read of that tile, nine steps before G2(j)'s first.
+    // Round 4, from the ISA of the round-3 loop: (i) the activation arithmetic has no side effects, so nothing tied it to the place
+    // it was written at - hipcc sank all 32 activations of a chunk (~500 VALU instructions, 32 v_exp + 32 v_rcp) into the ONE step
+    // that stores them, where they ran with the matrix pipe idle: every activation pair now ends in an `asm volatile` use of its
+    // packed result, which pins it between the MFMAs it was meant to hide under; (ii) the walk is STATIC - a step knows at compile
+    // time which tile is four ahead and how many DMA pieces are in flight, so the ~40 scalar instructions (and the branches) per step
+    // that recomputed this from the tile counter are gone; (iii) the GEGLU-1 bias enters as the C operand of the chunk's first
+    // MFMAs instead of two v_add per activation.
+    // GEMM-1 tile: 256 interleaved (a, g) columns = 64 per wave (FN = 4): a lane's 16 consecutive columns are 8 (a, g) pairs = the
+    // 8 activations of hidden units wn*32 + g*8 .. +7 of one fragment row - one 16-B chunk of the activation tile.
+    f4 b1v[4];
+    unsigned oreg[4][4];  // [fragment row][pair]: two fp16 activations each
+    h8 afS[2][4], wfS[2][5];
     auto load_b1 = [&](int jc) {
-      const float* bp = p.b1 + jc * 256 + wn * 128 + g * 32;
+      const float* bp = p.b1 + jc * 256 + wn * 64 + g * 16;
 #pragma unroll
-      for (int b = 0; b < 8; b++) b1v[b] = *(const f4*)(bp + b * 4);
+      for (int b = 0; b < 4; b++) b1v[b] = *(const f4*)(bp + b * 4);
     };
-    auto act_unit = [&](int u, int j0, int j1) {  // elements j0..j1-1 of unit u = (a, q): 8 activations = one 16-B chunk
-      const int a = u >> 1, q = u & 1;
-#pragma unroll
-      for (int j = j0; j < j1; j++) {
-        const int b = q * 4 + (j >> 1), r = (j & 1) * 2;
-        oreg[a][q][j] = (half_t)((acc[a][b][r] + b1v[b][r]) * gelu_tanh_c(acc[a][b][r + 1] + b1v[b][r + 1]));
-      }
+    // activations 2*jp and 2*jp+1 of fragment row u: hidden units (a, g) = (acc[u][jp][0], [1]) and ([2], [3]); the bias is already
+    // in the accumulator.  The asm use keeps the arithmetic HERE (see (i) above).
+    auto act_pair = [&](int u, int jp) {
+      const f4 v = acc[u][jp];
+      const float o0 = v[0] * gelu_tanh_c(v[1]), o1 = v[2] * gelu_tanh_c(v[3]);
+      h2 pk = {(half_t)o0, (half_t)o1};
+      oreg[u][jp] = pin_here(__builtin_bit_cast(unsigned, pk));
     };
     auto write_act = [&]() {
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-          *(h8*)(smem + ACT_OFF + wn * A_KT + (wm * 32 + a * 16 + rsel) * 128 + (((g * 2 + q) ^ key) << 4)) = oreg[a][q];
+      for (int a = 0; a < 4; a++)
+        *(u4v*)(smem + ACT_OFF + (wn >> 1) * A_KT + (a * 16 + rsel) * 128 + ((((wn & 1) * 4 + g) ^ key) << 4)) =
+            u4v{oreg[a][0], oreg[a][1], oreg[a][2], oreg[a][3]};
     };
-    constexpr int F_ZERO = 1, F_EXTRA = 2, F_WRITE = 4, F_PLAIN = 8;
-    // PK / CK: kind of the previous / current tile (0 none, 1 = GEMM-1 tile: 256 rows, FN 8, A from the LN tile ; 2 = GEMM-2
-    // tile: 320 rows, FN 10, A from the activation tile) ; KC: index of the current tile in its GEMM ; SET: fragment register
+    constexpr int F_BIAS = 1, F_EXTRA = 2, F_WRITE = 4, F_PLAIN = 8;
+    constexpr int FB = SEG0_BYTES + 10 * TILE_FULL;  // byte offset of chunk 0's tiles in the stream
+    int jb = FB;                                      // ... of the current chunk j's
+    // PK / CK: kind of the previous / current tile (0 none, 1 = GEMM-1 tile: 256 rows, FN 4, A from the LN tile ; 2 = GEMM-2
+    // tile: 320 rows, FN 5, A from the activation tile) ; KC: index of the current tile in its GEMM ; SET: fragment register
     // set the current tile's fragments go to ; FILL: activation unit computed under this step's MFMAs (-1 none)
-    auto gstep = [&](auto pk_c, auto ck_c, auto kc_c, auto set_c, auto fill_c, auto flags_c) {
+    // LK / LOFF: the tile four ahead (the one this step's DMA pieces fetch): kind (1 / 2 as above, 0 = none) and byte offset relative to jb
+    // YG: pieces of the three tiles behind the current one that may stay in flight (4 per GEMM-1 tile, 5 per full tile)
+    auto gstep = [&](auto pk_c, auto ck_c, auto kc_c, auto set_c, auto fill_c, auto flags_c, auto lk_c, auto loff_c, auto yg_c) {
       constexpr int PK = decltype(pk_c)::value, CK = decltype(ck_c)::value, KC = decltype(kc_c)::value, SET = decltype(set_c)::value;
       constexpr int FILL = decltype(fill_c)::value, FLAGS = decltype(flags_c)::value;
-      constexpr int FNp = PK == 1 ? 8 : 10, FNc = CK == 1 ? 8 : 10;
-      bool g1n = false, liven = false;
-      int off = 0, s4 = 0;
+      constexpr int LK = decltype(lk_c)::value, LOFF = decltype(loff_c)::value, YG = decltype(yg_c)::value;
+      constexpr int FNp = PK == 1 ? 4 : 5, FNc = CK == 1 ? 4 : 5;
+      constexpr bool G1N = LK == 1;
+      int s4 = 0;
       const char *sA = smem, *sW = smem;
       if constexpr (CK != 0) {
-        int younger = 0;
-#pragma unroll
-        for (int d = 1; d <= 3; d++) { bool yg1, ylive; tile_off(1, gt + d, yg1, ylive); younger += yg1 ? 4 : 5; }
-        constexpr int EX = (FLAGS & F_EXTRA) ? 8 : 0;
-        switch (younger) {
-          case 12: wait_vm<12 + EX>(); break;
-          case 13: wait_vm<13 + EX>(); break;
-          case 14: wait_vm<14 + EX>(); break;
-          default: wait_vm<15 + EX>(); break;
-        }
+        constexpr int EX = (FLAGS & F_EXTRA) ? 4 : 0;
+        wait_vm<YG + EX>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile gt-1 (and any activation-tile writes) are complete
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         sA = smem + (CK == 1 ? A_OFF : ACT_OFF) + (KC >> 1) * A_KT + a_rd + ((((KC & 1) * 4 + g) ^ key) << 4);
-        sW = smem + RING_OFF + sl * SLOT + wn * (FNc == 10 ? 10240 : 8192) + w_rd;
-        off = tile_off(1, gt + 4, g1n, liven);
+        sW = smem + RING_OFF + sl * SLOT + wn * (FNc == 5 ? 5120 : 4096) + w_rd;
         s4 = sl == 0 ? 4 : sl - 1;
       }
+      const int off = jb + LOFF;
+      auto dma = [&](int i) {  // piece i of the tile four ahead (a GEMM-1 tile has 16 pieces: 4 per wave)
+        if constexpr (CK != 0 && LK != 0) { if (!(G1N && i == 4)) piece(off, G1N, true, s4, i); }
+      };
       if constexpr ((FLAGS & F_WRITE) != 0) write_act();
-      h8 (&af)[2] = afS[SET];
-      h8 (&wf)[10] = wfS[SET];
-      const h8 (&paf)[2] = afS[SET ^ 1];
-      const h8 (&pwf)[10] = wfS[SET ^ 1];
+      h8 (&af)[4] = afS[SET];
+      h8 (&wf)[5] = wfS[SET];
+      const h8 (&paf)[4] = afS[SET ^ 1];
+      const h8 (&pwf)[5] = wfS[SET ^ 1];
       if constexpr (PK == 0) {
         if constexpr (CK != 0) {
 #pragma unroll
-          for (int a = 0; a < 2; a++) af[a] = *(const h8*)(sA + a * 2048);
+          for (int a = 0; a < 4; a++) af[a] = *(const h8*)(sA + a * 2048);
 #pragma unroll
           for (int b = 0; b < FNc; b++) wf[b] = *(const h8*)(sW + b * 1024);
 #pragma unroll
-          for (int i = 0; i < 5; i++) if (!(g1n && i == 4)) piece(off, g1n, liven, s4, i);
+          for (int i = 0; i < 5; i++) dma(i);
         }
       } else {
-        constexpr int NM = 2 * FNp, NR = CK != 0 ? 2 + FNc : 0;
+        constexpr int NM = 4 * FNp, NR = CK != 0 ? 4 + FNc : 0;
 #pragma unroll
         for (int q = 0; q < NM; q++) {
-          const int b = q >> 1, a = q & 1;
-          const f4 c0 = (FLAGS & F_ZERO) ? f4{0.f, 0.f, 0.f, 0.f} : (PK == 1 ? acc[a][b] : acc2[a][b]);
-          const f4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], c0, 0, 0, 0);
-          if (PK == 1) acc[a][b] = d; else acc2[a][b] = d;
+          const int b = q >> 2, a = q & 3;
+          if constexpr (PK == 1) {
+            const f4 c0 = (FLAGS & F_BIAS) ? b1v[b] : acc[a][b];  // first products of a chunk: the GEGLU-1 bias is the C operand
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], c0, 0, 0, 0);
+          } else {
+            acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], acc2[a][b], 0, 0, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (q < NR) {
-            if (q < 2) af[q] = *(const h8*)(sA + q * 2048);
-            else wf[q - 2] = *(const h8*)(sW + (q - 2) * 1024);
+            if (q < 4) af[q] = *(const h8*)(sA + q * 2048);
+            else wf[q - 4] = *(const h8*)(sW + (q - 4) * 1024);
           }
-          if (CK != 0 && (q + 1) % (NM / 5) == 0 && (q + 1) / (NM / 5) - 1 < 5) {
-            const int i = (q + 1) / (NM / 5) - 1;
-            if (!(g1n && i == 4)) piece(off, g1n, liven, s4, i);
-          }
-          // one activation after every second MFMA (8 per step)
-          if (FILL >= 0 && (q & 1) && (q >> 1) < 8) act_unit(FILL, q >> 1, (q >> 1) + 1);
+          if ((q + 1) % (NM / 5) == 0 && (q + 1) / (NM / 5) - 1 < 5) dma((q + 1) / (NM / 5) - 1);
+          // one activation pair after every fifth MFMA (4 per step = one fragment row)
+          if (FILL >= 0 && NM == 20 && q % 5 == 4) act_pair(FILL, q / 5);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr ((FLAGS & F_PLAIN) != 0) {  // chunk 0: nothing to hide its activation under
 #pragma unroll
-        for (int u = 0; u < 4; u++) act_unit(u, 0, 8);
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int jp = 0; jp < 4; jp++) act_pair(u, jp);
         write_act();
       }
       if constexpr (CK != 0) {
@@ -800,123 +820,120 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         sl = sl == 4 ? 0 : sl + 1;
       }
     };
-    using IM1 = std::integral_constant<int, -1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    using I4 = std::integral_constant<int, 4>;
-    using I5 = std::integral_constant<int, 5>;
-    using I6 = std::integral_constant<int, 6>;
-    using I7 = std::integral_constant<int, 7>;
-    using I9 = std::integral_constant<int, 9>;
-    // ---- G1(0): tiles 0..9 (bias of chunk 0 in flight under its first four steps) ----
+    // compile-time description of the walk.  Position P of a chunk iteration j (1..9): P < 10 = tile P of G1(j), else tile P-10 of
+    // G2(j-1).  The tile D positions ahead: same iteration while P + D < 14, else the next iteration's G1(j+1) (LAST: G2(9)).
+    // Offsets are relative to jb = the byte offset of chunk j.
+#define TSD_IC(x) std::integral_constant<int, (x)>{}
+    auto la_kind = [](int pd, bool last) constexpr { return pd < 10 ? 1 : (pd < 14 ? 2 : (last ? 2 : 1)); };
+    auto la_off = [](int pd, bool last) constexpr {
+      return pd < 10 ? pd * TILE_G1
+                     : (pd < 14 ? -FFN_CHUNK_BYTES + 10 * TILE_G1 + (pd - 10) * TILE_FULL
+                                : (last ? 10 * TILE_G1 + (pd - 14) * TILE_FULL : FFN_CHUNK_BYTES + (pd - 14) * TILE_G1));
+    };
+    auto la_yg = [=](int p_, bool last) constexpr {
+      int y = 0;
+      for (int d = 1; d <= 3; d++) y += la_kind(p_ + d, last) == 1 ? 4 : 5;
+      return y;
+    };
+    // one chunk iteration: FIRST (j = 1: the previous tile is G1(0)'s last, chunk 0's activation runs in the open), LAST (j = 9)
+    auto iteration = [&](auto first_c, auto last_c) {
+      constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+#define TSD_LA(P) TSD_IC(la_kind((P) + 4, LAST)), TSD_IC(la_off((P) + 4, LAST)), TSD_IC(la_yg((P), LAST))
+      // ---- G1(j): the first step finishes the previous tile (G1(0)'s last for j = 1; else G2(j-2)'s last, hiding fragment row 3 of
+      // chunk j-1's activation) ; the second publishes chunk j-1's activations ----
+      if constexpr (FIRST) gstep(TSD_IC(1), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(F_PLAIN), TSD_LA(0));
+      else gstep(TSD_IC(2), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_IC(3), TSD_IC(0), TSD_LA(0));
+      gstep(TSD_IC(1), TSD_IC(1), TSD_IC(1), TSD_IC(1), TSD_IC(-1), TSD_IC(FIRST ? F_BIAS : F_BIAS | F_WRITE), TSD_LA(1));
+      gstep(TSD_IC(1), TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA(2));
+      gstep(TSD_IC(1), TSD_IC(1), TSD_IC(3), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA(3));
+      gstep(TSD_IC(1), TSD_IC(1), TSD_IC(4), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA(4));
+      if constexpr (!LAST) {
+        load_b1((jb - FB) / FFN_CHUNK_BYTES + 1);                // the next chunk's bias: its C operand five steps into the next iteration
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(5), TSD_IC(1), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA(5));  // EXTRA for four steps
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(6), TSD_IC(0), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA(6));
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(7), TSD_IC(1), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA(7));
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(8), TSD_IC(0), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA(8));
+      } else {
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(5), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA(5));
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(6), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA(6));
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(7), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA(7));
+        gstep(TSD_IC(1), TSD_IC(1), TSD_IC(8), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA(8));
+      }
+      gstep(TSD_IC(1), TSD_IC(1), TSD_IC(9), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA(9));
+      // ---- G2(j-1): chunk j's activation, fragment rows 0..2, under its tiles' MFMAs ----
+      gstep(TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA(10));
+      gstep(TSD_IC(2), TSD_IC(2), TSD_IC(1), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_LA(11));
+      gstep(TSD_IC(2), TSD_IC(2), TSD_IC(2), TSD_IC(0), TSD_IC(1), TSD_IC(0), TSD_LA(12));
+      gstep(TSD_IC(2), TSD_IC(2), TSD_IC(3), TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_LA(13));
+#undef TSD_LA
+    };
+    // ---- G1(0): tiles 0..9 (bias of chunk 0 in flight under its first steps; the tile four ahead is G1(0)'s own, then G1(1)'s) ----
     load_b1(0);
-    gstep(I0{}, I1{}, I0{}, I0{}, IM1{}, I2{});                 // flags: EXTRA
-    gstep(I1{}, I1{}, I1{}, I1{}, IM1{}, I3{});                 // ZERO (first product of the chunk) + EXTRA
-    gstep(I1{}, I1{}, I2{}, I0{}, IM1{}, I2{});
-    gstep(I1{}, I1{}, I3{}, I1{}, IM1{}, I2{});
-    gstep(I1{}, I1{}, I4{}, I0{}, IM1{}, I0{});
-    gstep(I1{}, I1{}, I5{}, I1{}, IM1{}, I0{});
-    gstep(I1{}, I1{}, I6{}, I0{}, IM1{}, I0{});
-    gstep(I1{}, I1{}, I7{}, I1{}, IM1{}, I0{});
-    gstep(I1{}, I1{}, I8{}, I0{}, IM1{}, I0{});
-    gstep(I1{}, I1{}, I9{}, I1{}, IM1{}, I0{});
-    for (int j = 1; j < 10; j++) {
-      // ---- G1(j): the first step finishes the previous tile (G1(0)'s last for j = 1: then chunk 0's activation runs in the
-      // open; else G2(j-2)'s last, hiding unit 3 of chunk j-1) ; the second publishes chunk j-1's activations ----
-      if (j == 1) gstep(I1{}, I1{}, I0{}, I0{}, IM1{}, I8{});   // PLAIN: all of chunk 0's activation + write
-      else gstep(I2{}, I1{}, I0{}, I0{}, I3{}, I0{});
-      if (j == 1) gstep(I1{}, I1{}, I1{}, I1{}, IM1{}, I1{});   // ZERO
-      else gstep(I1{}, I1{}, I1{}, I1{}, IM1{}, I5{});          // ZERO + WRITE
-      gstep(I1{}, I1{}, I2{}, I0{}, IM1{}, I0{});
-      gstep(I1{}, I1{}, I3{}, I1{}, IM1{}, I0{});
-      gstep(I1{}, I1{}, I4{}, I0{}, IM1{}, I0{});
-      load_b1(j);                                               // used from the second step of G2(j-1) on: six steps from here
-      gstep(I1{}, I1{}, I5{}, I1{}, IM1{}, I2{});               // EXTRA for four steps
-      gstep(I1{}, I1{}, I6{}, I0{}, IM1{}, I2{});
-      gstep(I1{}, I1{}, I7{}, I1{}, IM1{}, I2{});
-      gstep(I1{}, I1{}, I8{}, I0{}, IM1{}, I2{});
-      gstep(I1{}, I1{}, I9{}, I1{}, IM1{}, I0{});
-      // ---- G2(j-1): chunk j's activation units 0..2 under its tiles' MFMAs ----
-      gstep(I1{}, I2{}, I0{}, I0{}, IM1{}, I0{});
-      gstep(I2{}, I2{}, I1{}, I1{}, I0{}, I0{});
-      gstep(I2{}, I2{}, I2{}, I0{}, I1{}, I0{});
-      gstep(I2{}, I2{}, I3{}, I1{}, I2{}, I0{});
+#define TSD_LA0(P) TSD_IC(1), TSD_IC((P) + 4 < 10 ? ((P) + 4) * TILE_G1 : FFN_CHUNK_BYTES + ((P) + 4 - 10) * TILE_G1), TSD_IC(12)
+    gstep(TSD_IC(0), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA0(0));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(1), TSD_IC(1), TSD_IC(-1), TSD_IC(F_BIAS), TSD_LA0(1));   // its MFMAs read b1v: the compiler waits for it
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA0(2));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(3), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA0(3));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(4), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA0(4));
+    load_b1(1);
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(5), TSD_IC(1), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA0(5));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(6), TSD_IC(0), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA0(6));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(7), TSD_IC(1), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA0(7));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(8), TSD_IC(0), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA0(8));
+    gstep(TSD_IC(1), TSD_IC(1), TSD_IC(9), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA0(9));
+#undef TSD_LA0
+    jb = FB + FFN_CHUNK_BYTES;
+    iteration(std::true_type{}, std::false_type{});
+    for (int j = 2; j < 9; j++) {
+      jb += FFN_CHUNK_BYTES;
+      iteration(std::false_type{}, std::false_type{});
     }
-    // ---- G2(8)'s last tile with unit 3 of chunk 9, publish, then G2(9) ----
-    gstep(I2{}, I0{}, I0{}, I0{}, I3{}, I0{});
-    // that step had no tile barrier (CK = 0): G2(8)'s last reads of the activation tile by the OTHER column wave must have retired
-    // before this wave overwrites its rows with chunk 9 (inside the loop the publish sits two barriers behind the last read)
+    jb += FFN_CHUNK_BYTES;
+    iteration(std::false_type{}, std::true_type{});
+    // ---- G2(8)'s last tile with fragment row 3 of chunk 9's activation, publish, then G2(9); four ahead: the conv_out tiles ----
+    // (offsets relative to jb = chunk 9: the Wout tiles follow chunk 9's fourteen)
+    gstep(TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(0), TSD_IC(3), TSD_IC(0), TSD_IC(0), TSD_IC(0), TSD_IC(0));
+    // that step had no tile barrier (CK = 0): G2(8)'s last reads of the activation tile by the OTHER waves must have retired
+    // before this wave overwrites its columns with chunk 9 (inside the loop the publish sits two barriers behind the last read)
     lds_barrier();
     write_act();
-    gstep(I0{}, I2{}, I0{}, I0{}, IM1{}, I0{});
-    gstep(I2{}, I2{}, I1{}, I1{}, IM1{}, I0{});
-    gstep(I2{}, I2{}, I2{}, I0{}, IM1{}, I0{});
-    gstep(I2{}, I2{}, I3{}, I1{}, IM1{}, I0{});
-    gstep(I2{}, I0{}, I0{}, I0{}, IM1{}, I0{});
+    gstep(TSD_IC(0), TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 0 * TILE_FULL), TSD_IC(15));
+    gstep(TSD_IC(2), TSD_IC(2), TSD_IC(1), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 1 * TILE_FULL), TSD_IC(15));
+    gstep(TSD_IC(2), TSD_IC(2), TSD_IC(2), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 2 * TILE_FULL), TSD_IC(15));
+    gstep(TSD_IC(2), TSD_IC(2), TSD_IC(3), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 3 * TILE_FULL), TSD_IC(15));
+    gstep(TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_IC(0), TSD_IC(0), TSD_IC(0));
+#undef TSD_IC
   }
-#else
-  for (int jc = 0; jc < 10; jc++) {
-    if (jc == 5) CTS(10);
-    f4 b1v[8];  // this chunk's (a, g) bias pairs: in flight under the chunk's first GEMM
-    {
-      const float* bp = p.b1 + jc * 256 + wn * 128 + g * 32;
-#pragma unroll
-      for (int b = 0; b < 8; b++) b1v[b] = *(const f4*)(bp + b * 4);
-    }
-    gemm(I8{}, I1{}, Yes{}, I8{}, acc, A_OFF, 10, No{});  // (a, g) interleaved: 256 columns
-    if (jc == 5) CTS(11);
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const int row = wm * 32 + a * 16 + rsel;
-#pragma unroll
-      for (int q = 0; q < 2; q++) {  // 16 activations per lane and fragment row = two 16-B chunks
-        h8 o;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int b = q * 4 + (j >> 1), r = (j & 1) * 2;
-          o[j] = (half_t)((acc[a][b][r] + b1v[b][r]) * gelu_tanh_c(acc[a][b][r + 1] + b1v[b][r + 1]));
-        }
-        *(h8*)(smem + ACT_OFF + wn * A_KT + row * 128 + (((g * 2 + q) ^ key) << 4)) = o;
-      }
-    }
-    // the tile barrier that opens the next GEMM makes the activations visible (and the 10 tile barriers of the next
-    // chunk's first GEMM separate this chunk's reads from the next chunk's writes)
-    if (jc == 5) CTS(12);
-    gemm(I10{}, I1{}, No{}, I0{}, acc2, ACT_OFF, 4, No{});
-    if (jc == 5) CTS(13);
-  }
-#endif
   CTS(7);
   load_cols(p.b2, bv);
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 10; b++) T[a][b] += acc2[a][b] + bv[b];
+    for (int b = 0; b < 5; b++) T[a][b] += acc2[a][b] + bv[b];
   // tok4 -> A tile (every wave passed the last GEGLU-1 tile long ago: the A tile is free)
-  store_a_tile(T, 1.f, 0.f, 1.f, 0.f);
+  store_a_tile(T, one4, zero4);
   // ---- out = tok4 . Wout^T + b + x --------------------------------------------------------------------------------
   load_cols(p.bout, bv);
   load_rows_raw(p.x, p.ld_x, raw);
-  gemm(I10{}, I1{}, Yes{}, I20{}, acc, A_OFF, 10, No{});
+  gemm(I1{}, Yes{}, I25{}, acc, A_OFF, 10, No{});
   CTS(8);
-  float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 groups of 10 channels
+  float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // [32-row slab][this lane's 2 groups of 10 channels]
   lds_barrier();  // every wave is done with the A tile: it (and the idle activation tile behind it) stages the output rows
-  constexpr int RP = 656;  // row pitch of the row-major staging tile: conflict-free 16-B writes, whole-row global stores
+  constexpr int RP = 656;  // row pitch of the row-major staging tile, whole-row global stores
   static_assert(A_OFF + 64 * RP <= RING_OFF, "output staging must stay clear of the ring (dead DMAs may still land there)");
 #pragma unroll
-  for (int a = 0; a < 2; a++) {
+  for (int a = 0; a < 4; a++) {
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
-      h8 o;
+    for (int b = 0; b < 5; b++) {
+      h4 o;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int b = 2 * q + (j >> 2), r = j & 3;
-        o[j] = (half_t)((float)raw[a][q][j] + (acc[a][b][r] + bv[b][r]));
-        const float f = (float)o[j];
-        const int grp = (q * 8 + j) / 10;
-        gs1[grp] += f; gs2[grp] += f * f;
+      for (int r = 0; r < 4; r++) {
+        o[r] = (half_t)((float)raw[a][b][r] + (acc[a][b][r] + bv[b][r]));
+        const float f = (float)o[r];
+        const int grp = (b * 4 + r) / 10;
+        gs1[a >> 1][grp] += f; gs2[a >> 1][grp] += f * f;
       }
-      *(h8*)(smem + A_OFF + (wm * 32 + a * 16 + rsel) * RP + (cbase + q * 8) * 2) = o;
+      *(h4*)(smem + A_OFF + (a * 16 + rsel) * RP + (cbase + b * 4) * 2) = o;
     }
   }
   lds_barrier();
@@ -926,17 +943,21 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     *(h8*)(p.out + (long long)(m0 + row) * p.ld_out + c * 8) = *(const h8*)(smem + A_OFF + row * RP + c * 16);
   }
   if (p.gn_part) {
-    // GroupNorm(32) statistics of the rounded output for the consumer (one 32-row slab per wave row block)
+    // GroupNorm(32) statistics of the rounded output for the consumer (one 32-row slab per pair of fragment rows)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int s = 0; s < 2; s++)
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { gs1[k] += __shfl_xor(gs1[k], o); gs2[k] += __shfl_xor(gs2[k], o); }
-    }
+      for (int k = 0; k < 2; k++) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { gs1[s][k] += __shfl_xor(gs1[s][k], o); gs2[s][k] += __shfl_xor(gs2[s][k], o); }
+      }
     if (rsel == 0) {
-      const int mrow = m0 + wm * 32, bb = mrow / p.S, slab = (mrow - bb * p.S) >> 5;
-      float* ob = p.gn_part + (((long long)bb * p.gn_nslab + slab) * 32 + wn * 16 + g * 4) * 2;
 #pragma unroll
-      for (int k = 0; k < 4; k++) *(f2*)(ob + k * 2) = f2{gs1[k], gs2[k]};
+      for (int s = 0; s < 2; s++) {
+        const int mrow = m0 + s * 32, bb = mrow / p.S, slab = (mrow - bb * p.S) >> 5;
+        float* ob = p.gn_part + (((long long)bb * p.gn_nslab + slab) * 32 + wn * 8 + g * 2) * 2;
+        *(f4*)ob = f4{gs1[s][0], gs2[s][0], gs1[s][1], gs2[s][1]};
+      }
     }
   }
   }

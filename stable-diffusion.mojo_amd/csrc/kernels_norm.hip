@@ -17,6 +17,7 @@
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int GN_MAX_CPT = 2;  // chunks (of 8 channels) per thread: C <= 4096
 constexpr int GN_UNROLL = 4;   // independent 16-B loads in flight per thread
@@ -123,14 +124,24 @@ __global__ __launch_bounds__(256) void k_gn_partial(const GnK p) {
 __device__ __forceinline__ void gn_finish_groups(const GnK& p, int b, int g0, int tid, float* out) {
   const int g = g0 + (tid >> 3), sl = tid & 7;
   double t1 = 0.0, t2 = 0.0;
-  if (g < p.G)
+  if (g < p.G && p.comb <= 1 && !p.partial1) {
+    // a lane's slab partials all in flight at once (16 per batch = 128 slabs, the 64x64 level): with four per batch the loop
+    // exposed one L2 / Infinity-Cache round trip per four slabs - 7-8 us for a kernel that reads 32 KB per sample (round 4).
+    // Same values added in the same order: bitwise the old result.
+    for (int s0 = sl; s0 < p.nslab; s0 += 128) {
+      f2 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int s = s0 + 8 * i;
+        v[i] = s < p.nslab ? *(const f2*)(p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2) : f2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) { t1 += (double)v[i][0]; t2 += (double)v[i][1]; }
+    }
+  } else if (g < p.G)
 #pragma unroll 4
     for (int s = sl; s < p.nslab; s += 8) {
-      if (p.comb <= 1 && !p.partial1) {
-        const float* o = p.partial + (((int64_t)b * p.nslab + s) * p.G + g) * 2;
-        t1 += (double)o[0];
-        t2 += (double)o[1];
-      } else {
+      {
         for (int k = 0; k < p.comb; k++) {  // fixed order: deterministic
           const int f = g * p.comb + k;
           const float* o = f < p.G0 ? p.partial + (((int64_t)b * p.nslab + s) * p.G0 + f) * 2
@@ -309,7 +320,7 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
     hipLaunchKernelGGL(k_gn_prereduce, dim3(64, B), dim3(256), 0, ctx->stream, pre_part, pre_nslab, groups, k.partial);
     HIP_TRY(hipGetLastError());
   }
-  k.stats_ready = (int64_t)k.nslab * groups >= 2048 ? 1 : 0;
+  k.stats_ready = (int64_t)k.nslab * groups >= ctx->opt.gn_finalize_min ? 1 : 0;
   if (k.stats_ready) {
     hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);
     HIP_TRY(hipGetLastError());

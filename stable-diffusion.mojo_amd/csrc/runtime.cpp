@@ -42,6 +42,7 @@ void options_from_env(TsdOptions& o) {
   o.tune = env_int("TSD_GEMM_TUNE", o.tune);
   if (const char* ov = getenv("TSD_GEMM_CFG_OVERRIDE")) { strncpy(o.cfg_override, ov, sizeof(o.cfg_override) - 1); o.cfg_override[sizeof(o.cfg_override) - 1] = 0; }
   o.gn_apply_mult = env_int("TSD_GN_APPLY_MULT", o.gn_apply_mult);
+  o.gn_finalize_min = env_int("TSD_GN_FINALIZE_MIN", o.gn_finalize_min);
   o.debug_occ = getenv("TSD_DEBUG_OCC") ? 1 : 0;
   o.bench_wrot = env_int("TSD_BENCH_WROT", o.bench_wrot); if (o.bench_wrot < 1) o.bench_wrot = 1;
   o.bench_epi = env_int("TSD_BENCH_EPI", o.bench_epi);
