@@ -587,6 +587,10 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   wait_vm<5>();   // the context tiles have landed (the 5 bias loads are younger)
   lds_barrier();  // q tile and context tiles visible
   // per wave: all 64 rows, heads 2*wn and 2*wn+1 (its own 80 columns of q: no other wave reads or writes them)
+  const bool t_ge64 = p.T >= 64;  // wave-uniform: only key fragment 4 (keys 64 + 4g + r) can hold a key >= T
+  f4 mk4;
+#pragma unroll
+  for (int r = 0; r < 4; r++) mk4[r] = 64 + 4 * g + r >= p.T ? -1.0e30f : 0.f;
 #pragma unroll
   for (int hh = 0; hh < 2; hh++) {
     const int h = wn * 2 + hh, c0 = h * 5;  // first 16-B chunk of the head's 40 columns
@@ -613,38 +617,39 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
 #pragma unroll
         for (int b = 0; b < 5; b++) sc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb[b], qa[a], sc[a][b], 0, 0, 0);
     }
-    // softmax over the keys of each query row: 20 in-lane scores x 4 lane groups (max subtraction, App.A D6)
+    // softmax over the keys of each query row: 20 in-lane scores x 4 lane groups (max subtraction, App.A D6).
+    // Round 4, after reading the ISA (the phase was ~3000 VALU instructions per wave for 152 MFMAs): (i) keys >= T are masked by
+    // ADDING -1e30 to the one fragment that can hold them when T >= 64 (every other fragment only in the rare T < 64 case) instead of
+    // a compare + select per score; (ii) the row sum comes out of the P.V MFMAs - V^T row 40 of the head's third 16-row fragment
+    // (a discarded output channel) is replaced by ones, so output channel 40 is the sum of the SAME fp16-rounded probabilities the
+    // MFMA multiplies (as flash_attn_kernel's ones row) - instead of a convert-back and an add per probability.
     h8 pf[4][3];
-    float rinv[4];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-      float mx = -1.0e30f;
+      if (!t_ge64) {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (32 * (b >> 1) + 8 * g + 4 * (b & 1) + r >= p.T) sc[a][b][r] = -1.0e30f;
+      }
+      sc[a][4] += mk4;
+      float mx = sc[a][0][0];
 #pragma unroll
       for (int b = 0; b < 5; b++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int kidx = b < 4 ? 32 * (b >> 1) + 8 * g + 4 * (b & 1) + r : 64 + 4 * g + r;
-          if (kidx >= p.T) sc[a][b][r] = -1.0e30f;
-          mx = fmaxf(mx, sc[a][b][r]);
-        }
+        for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[a][b][r]);
       mx = rows_max(mx);
-      float sum = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) {
-        h8 o;
+        h8 o = h8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          half_t ph = (half_t)0.f;
-          if (kk < 2 || j < 4) ph = (half_t)__builtin_amdgcn_exp2f(sc[a][kk < 2 ? 2 * kk + (j >> 2) : 4][j & 3] - mx);
-          o[j] = ph;
-          sum += (float)ph;  // the normaliser sums the SAME rounded probabilities the MFMA multiplies
-        }
+        for (int j = 0; j < (kk < 2 ? 8 : 4); j++) o[j] = (half_t)__builtin_amdgcn_exp2f(sc[a][kk < 2 ? 2 * kk + (j >> 2) : 4][j & 3] - mx);
         pf[a][kk] = o;
       }
-      sum = rows_sum(sum);
-      rinv[a] = 1.f / sum;
     }
-    // O_h = P . V_h : channel rows h*40 + b*16 + rsel of the V^T tiles (rows past the head's 40 give discarded outputs)
+    // O_h = P . V_h : channel rows h*40 + b*16 + rsel of the V^T tiles (rows past the head's 40 give discarded outputs - except
+    // row 40, which is the ones row: lane group 2, register 0 of fragment 2 then holds the row sum)
     f4 oc[4][3];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -662,11 +667,15 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
           vb[b] = h8{lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
         }
       }
+      if (rsel == 8) vb[2] = kk < 2 ? h8{1, 1, 1, 1, 1, 1, 1, 1} : h8{1, 1, 1, 1, 0, 0, 0, 0};
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) oc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[b], pf[a][kk], oc[a][b], 0, 0, 0);
     }
+    float rinv[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) rinv[a] = 1.f / rows_sum(g == 2 ? oc[a][2][0] : 0.f);
     // The head's output overwrites the head's q columns in the A tile.  Columns h*40 .. h*40+39 are read (as q) and written by
     // THIS wave only, and its QK^T for this head is done, so no barrier is needed.  lane (g, r) of fragment b holds channel
     // h*40 + b*16 + 4g + r.
