@@ -100,6 +100,7 @@ struct tsd_ctx {
   bool profile = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
   std::vector<int> prof_cls;
+  std::vector<int> prof_kern;   // kernel dispatches per record
   std::vector<int> prof_shape;  // 4 ints per record (M, N, K, batch) - 0 when not a GEMM
   size_t prof_n = 0;
 };
@@ -111,6 +112,7 @@ enum KernelClass : int {
 // RAII: records a start/stop event pair around the launches in its scope when profiling is on
 struct ProfScope {
   tsd_ctx* c; bool on;
+  int kernels = 1;  // kernel dispatches inside the scope (a GroupNorm scope brackets up to three): what profile_end counts as launches
   ProfScope(tsd_ctx* ctx, int cls, int M = 0, int N = 0, int K = 0, int batch = 0)
       : c(ctx), on(ctx->profile && ctx->launch()) {
     if (!on) return;
@@ -128,6 +130,8 @@ struct ProfScope {
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(c->prof_ev[c->prof_n * 2 + 1], c->stream);
+    if (c->prof_kern.size() <= c->prof_n) c->prof_kern.resize(c->prof_n + 1);
+    c->prof_kern[c->prof_n] = kernels;
     c->prof_n++;
   }
 };

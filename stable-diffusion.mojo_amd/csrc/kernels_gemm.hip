@@ -1302,7 +1302,7 @@ static int choose_cfg(const TsdOptions& o, int M, int N, int K, int batch, bool 
   }
   if ((tune & 1) && !conv && n160 && K >= 256 && (t256 == 256 || t256 == 512) && M % 256 == 0) return 11;
   if (t128 >= 512) return n160 ? 0 : 2;
-  // Round 3 (late), measured INSIDE the step (TSD_GEMM_CFG_OVERRIDE + scripts/instep_sweep.sh; the repeated-launch microbenchmark
+  // Round 3 (late), measured INSIDE the step (TSD_GEMM_CFG_OVERRIDE + experiments/drivers/instep_sweep.sh; the repeated-launch microbenchmark
   // keeps the operands in the L2 and ranks these the other way round): dense GEMMs with exactly one 128-row tile per CU run the
   // staggered 128x160 tile with loader waves (54: 8192x640x640 19.4 -> 17.7 us, 8192x640x2560 42 -> 39.7 us), and the 256-tile
   // 64-row problems of the 16x16 level the 64x160 tile with loader waves (47: 2048x1280x1280 20.2 -> 19.2 us); TSD_GEMM_TUNE bit 3

@@ -313,6 +313,8 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
   k.aw = aff ? aff->w : nullptr; k.ab = aff ? aff->b : nullptr; k.torch_rstd = aff ? aff->torch_rstd : 0;
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
+  k.stats_ready = (int64_t)k.nslab * groups >= ctx->opt.gn_finalize_min ? 1 : 0;
+  prof.kernels = 1 + ((!have_stats || prereduce) ? 1 : 0) + (k.stats_ready ? 1 : 0);
   if (!have_stats) {
     hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
     HIP_TRY(hipGetLastError());
@@ -320,7 +322,6 @@ int launch_groupnorm(tsd_ctx* ctx, const NormSrc& src, int B, int HW, int C, int
     hipLaunchKernelGGL(k_gn_prereduce, dim3(64, B), dim3(256), 0, ctx->stream, pre_part, pre_nslab, groups, k.partial);
     HIP_TRY(hipGetLastError());
   }
-  k.stats_ready = (int64_t)k.nslab * groups >= ctx->opt.gn_finalize_min ? 1 : 0;
   if (k.stats_ready) {
     hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);
     HIP_TRY(hipGetLastError());
@@ -361,6 +362,7 @@ int launch_gn_stats(tsd_ctx* ctx, const half_t* x, int ld, int B, int HW, int C,
   k.stats = stats; k.eps = eps; k.gamma = gamma;
   if (!ctx->launch()) return TSD_OK;
   ProfScope prof(ctx, KC_GROUPNORM, B * HW, C, 0, 1);
+  prof.kernels = 2;
   hipLaunchKernelGGL(k_gn_partial, dim3(k.nslab, B), dim3(256), (size_t)PL * 2 * C * sizeof(float), ctx->stream, k);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_gn_finalize, dim3(ceil_div(groups, 32), B), dim3(256), 0, ctx->stream, k);

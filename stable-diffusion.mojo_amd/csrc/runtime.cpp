@@ -183,7 +183,7 @@ extern "C" int tsd_ctx_profile_end(tsd_ctx* c, float* ms_per_class, int* launche
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
     const int k = c->prof_cls[i];
-    if (k >= 0 && k < nclass) { ms_per_class[k] += ms; launches_per_class[k]++; }
+    if (k >= 0 && k < nclass) { ms_per_class[k] += ms; launches_per_class[k] += i < c->prof_kern.size() ? c->prof_kern[i] : 1; }
   }
   c->prof_n = 0;
   return TSD_OK;
