@@ -32,6 +32,14 @@
 #include "common.h"
 #include "lds_dma.h"
 
+// Ablation builds of the GEGLU pipeline (timing only, results wrong): bit 0 no tile barrier, bit 1 no fragment reads, bit 2 no MFMAs,
+// bit 3 no DMA pieces, bit 4 no activation arithmetic, bit 5 no counted DMA wait
+#ifndef TSD_CHAIN_ABL
+#define TSD_CHAIN_ABL 0
+#endif
+#ifndef TSD_CHAIN_ARES
+#define TSD_CHAIN_ARES 5  // GEMM-1 k-tiles whose A fragments stay in registers through the feed-forward (0 = none)
+#endif
 #ifndef TSD_CHAIN_PIPE
 #define TSD_CHAIN_PIPE 1  // 0 = the round-2 per-chunk GEGLU loop (A/B builds)
 #endif
@@ -224,10 +232,13 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   const rsrc_t rw = make_rsrc(p.wstream, KIND == KIND_HEAD ? HEAD_STREAM_BYTES : STREAM_BYTES), rdead = make_rsrc(p.wstream, 0);
 #endif
   const unsigned lane16 = lane * 16;
-  // piece i (of 5 per wave) of tile gi -> ring slot: 1-KiB wave-instruction number wave + 4*i of the tile image
+  // piece i (of 5 per wave; 4 for a GEMM-1 tile) of tile gi -> ring slot.  Round 4: a wave fetches ITS OWN quarter of the tile image
+  // (bytes [wn * Q, wn * Q + Q), Q = 5 KiB / 4 KiB - exactly the weight rows its MFMAs read), so a wave's counted vmcnt wait is all it
+  // needs before it reads a tile, and a ring slot is only ever rewritten by the wave that read it: the tile loops run WITHOUT a
+  // barrier per tile (one barrier where the shared A operand changes hands instead of one per step: 140 -> 20 in the feed-forward).
   auto piece = [&](int off, bool g1, bool live, int slot, int i) {
-    const int j = wave + 4 * i;
-    const bool on = live && !(g1 && j >= 16);
+    const int j = wave * (g1 ? 4 : 5) + i;
+    const bool on = live && !(g1 && i >= 4);
 #ifdef TSD_CHAIN_NOPIECE  // ablation build: no DMA instructions at all after the first tiles of segment 1 (timing only)
     if (off >= SEG0_BYTES + 12 * TILE_FULL) return;
 #endif
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
           default: if (EXTRA > 0 && kt < 4) wait_vm<15 + EXTRA>(); else wait_vm<15>(); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile gt-1 are complete: its slot may be refilled
-        __builtin_amdgcn_s_barrier();
+        if (!have_prev) __builtin_amdgcn_s_barrier();        // stage start: the A operand every wave wrote a part of is complete
         asm volatile("" ::: "memory");
         sA = smem + a_base + (kt >> 1) * A_KT + a_rd + ((((kt & 1) * 4 + g) ^ key) << 4);
         sW = smem + RING_OFF + sl * SLOT + wn * 5120 + w_rd;
@@ -731,6 +742,18 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     f4 b1v[4];
     unsigned oreg[4][4];  // [fragment row][pair]: two fp16 activations each
     h8 afS[2][4], wfS[2][5];
+    // GEMM-1's A operand - LN(tok3), the same for all ten chunks - keeps the fragments of its first NRES k-tiles in registers for the
+    // whole feed-forward: those steps read 4 weight fragments instead of 4 + 4 (a ds_read_b128 holds a one-wave SIMD's issue ~30 cycles)
+    constexpr int NRES = TSD_CHAIN_ARES;
+    h8 ares[NRES > 0 ? NRES : 1][4];
+    if constexpr (NRES > 0) {
+      lds_barrier();  // LN(tok3) complete in the A tile (all four waves' columns)
+#pragma unroll
+      for (int kc = 0; kc < NRES; kc++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+          ares[kc][a] = *(const h8*)(smem + A_OFF + (kc >> 1) * A_KT + a_rd + a * 2048 + ((((kc & 1) * 4 + g) ^ key) << 4));
+    }
     auto load_b1 = [&](int jc) {
       const float* bp = p.b1 + jc * 256 + wn * 64 + g * 16;
 #pragma unroll
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         *(u4v*)(smem + ACT_OFF + (wn >> 1) * A_KT + (a * 16 + rsel) * 128 + ((((wn & 1) * 4 + g) ^ key) << 4)) =
             u4v{oreg[a][0], oreg[a][1], oreg[a][2], oreg[a][3]};
     };
-    constexpr int F_BIAS = 1, F_EXTRA = 2, F_WRITE = 4, F_PLAIN = 8;
+    constexpr int F_BIAS = 1, F_EXTRA = 2, F_WRITE = 4, F_PLAIN = 8, F_SYNC = 16;
     constexpr int FB = SEG0_BYTES + 10 * TILE_FULL;  // byte offset of chunk 0's tiles in the stream
     int jb = FB;                                      // ... of the current chunk j's
     // PK / CK: kind of the previous / current tile (0 none, 1 = GEMM-1 tile: 256 rows, FN 4, A from the LN tile ; 2 = GEMM-2
@@ -769,9 +792,11 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       const char *sA = smem, *sW = smem;
       if constexpr (CK != 0) {
         constexpr int EX = (FLAGS & F_EXTRA) ? 4 : 0;
-        wait_vm<YG + EX>();
+        if constexpr (!(TSD_CHAIN_ABL & 32)) wait_vm<YG + EX>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile gt-1 (and any activation-tile writes) are complete
-        __builtin_amdgcn_s_barrier();
+        // barriers only where the shared activation tile changes hands: before it is rewritten (F_WRITE steps: every wave has finished
+        // the previous chunk's GEMM-2 reads) and before its first GEMM-2 read (F_SYNC: every wave's part is written)
+        if constexpr ((FLAGS & (F_WRITE | F_SYNC)) != 0 && !(TSD_CHAIN_ABL & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         sA = smem + (CK == 1 ? A_OFF : ACT_OFF) + (KC >> 1) * A_KT + a_rd + ((((KC & 1) * 4 + g) ^ key) << 4);
         sW = smem + RING_OFF + sl * SLOT + wn * (FNc == 5 ? 5120 : 4096) + w_rd;
@@ -779,41 +804,47 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       }
       const int off = jb + LOFF;
       auto dma = [&](int i) {  // piece i of the tile four ahead (a GEMM-1 tile has 16 pieces: 4 per wave)
-        if constexpr (CK != 0 && LK != 0) { if (!(G1N && i == 4)) piece(off, G1N, true, s4, i); }
+        if constexpr (CK != 0 && LK != 0 && !(TSD_CHAIN_ABL & 8)) { if (!(G1N && i == 4)) piece(off, G1N, true, s4, i); }
       };
       if constexpr ((FLAGS & F_WRITE) != 0) write_act();
+      // register-resident A fragments: the current tile's are not read (CRES), the previous tile's come from ares (PRES)
+      constexpr int PKC = (CK == 1 && KC > 0) ? KC - 1 : 9;  // index of the previous tile when it is a GEMM-1 tile
+      constexpr bool CRES = CK == 1 && KC < NRES, PRES = PK == 1 && PKC < NRES;
       h8 (&af)[4] = afS[SET];
       h8 (&wf)[5] = wfS[SET];
-      const h8 (&paf)[4] = afS[SET ^ 1];
+      const h8 (&paf)[4] = PRES ? ares[PKC < NRES ? PKC : 0] : afS[SET ^ 1];
       const h8 (&pwf)[5] = wfS[SET ^ 1];
       if constexpr (PK == 0) {
         if constexpr (CK != 0) {
 #pragma unroll
-          for (int a = 0; a < 4; a++) af[a] = *(const h8*)(sA + a * 2048);
+          for (int a = 0; a < 4; a++) if (!CRES) af[a] = *(const h8*)(sA + a * 2048);
 #pragma unroll
           for (int b = 0; b < FNc; b++) wf[b] = *(const h8*)(sW + b * 1024);
 #pragma unroll
           for (int i = 0; i < 5; i++) dma(i);
         }
       } else {
-        constexpr int NM = 4 * FNp, NR = CK != 0 ? 4 + FNc : 0;
+        constexpr int NA = CRES ? 0 : 4;  // A fragments to read for the current tile
+        constexpr int NM = 4 * FNp, NR = CK != 0 ? NA + FNc : 0;
 #pragma unroll
         for (int q = 0; q < NM; q++) {
           const int b = q >> 2, a = q & 3;
-          if constexpr (PK == 1) {
+          if constexpr (TSD_CHAIN_ABL & 4) {
+            asm volatile("" ::"v"(pwf[b]), "v"(paf[a]));
+          } else if constexpr (PK == 1) {
             const f4 c0 = (FLAGS & F_BIAS) ? b1v[b] : acc[a][b];  // first products of a chunk: the GEGLU-1 bias is the C operand
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], c0, 0, 0, 0);
           } else {
             acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pwf[b], paf[a], acc2[a][b], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (q < NR) {
-            if (q < 4) af[q] = *(const h8*)(sA + q * 2048);
-            else wf[q - 4] = *(const h8*)(sW + (q - 4) * 1024);
+          if (q < NR && !(TSD_CHAIN_ABL & 2)) {
+            if (q < NA) af[q] = *(const h8*)(sA + q * 2048);
+            else wf[q - NA] = *(const h8*)(sW + (q - NA) * 1024);
           }
           if ((q + 1) % (NM / 5) == 0 && (q + 1) / (NM / 5) - 1 < 5) dma((q + 1) / (NM / 5) - 1);
           // one activation pair after every fifth MFMA (4 per step = one fragment row)
-          if (FILL >= 0 && NM == 20 && q % 5 == 4) act_pair(FILL, q / 5);
+          if (FILL >= 0 && NM == 20 && q % 5 == 4 && !(TSD_CHAIN_ABL & 16)) act_pair(FILL, q / 5);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -870,7 +901,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       }
       gstep(TSD_IC(1), TSD_IC(1), TSD_IC(9), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA(9));
       // ---- G2(j-1): chunk j's activation, fragment rows 0..2, under its tiles' MFMAs ----
-      gstep(TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA(10));
+      gstep(TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(F_SYNC), TSD_LA(10));
       gstep(TSD_IC(2), TSD_IC(2), TSD_IC(1), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_LA(11));
       gstep(TSD_IC(2), TSD_IC(2), TSD_IC(2), TSD_IC(0), TSD_IC(1), TSD_IC(0), TSD_LA(12));
       gstep(TSD_IC(2), TSD_IC(2), TSD_IC(3), TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_LA(13));
@@ -879,7 +910,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     // ---- G1(0): tiles 0..9 (bias of chunk 0 in flight under its first steps; the tile four ahead is G1(0)'s own, then G1(1)'s) ----
     load_b1(0);
 #define TSD_LA0(P) TSD_IC(1), TSD_IC((P) + 4 < 10 ? ((P) + 4) * TILE_G1 : FFN_CHUNK_BYTES + ((P) + 4 - 10) * TILE_G1), TSD_IC(12)
-    gstep(TSD_IC(0), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(F_EXTRA), TSD_LA0(0));
+    gstep(TSD_IC(0), TSD_IC(1), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(NRES > 0 ? F_EXTRA : F_EXTRA | F_SYNC), TSD_LA0(0));  // (the ares block's barrier published LN(tok3))
     gstep(TSD_IC(1), TSD_IC(1), TSD_IC(1), TSD_IC(1), TSD_IC(-1), TSD_IC(F_BIAS), TSD_LA0(1));   // its MFMAs read b1v: the compiler waits for it
     gstep(TSD_IC(1), TSD_IC(1), TSD_IC(2), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_LA0(2));
     gstep(TSD_IC(1), TSD_IC(1), TSD_IC(3), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_LA0(3));
@@ -906,7 +937,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     // before this wave overwrites its columns with chunk 9 (inside the loop the publish sits two barriers behind the last read)
     lds_barrier();
     write_act();
-    gstep(TSD_IC(0), TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 0 * TILE_FULL), TSD_IC(15));
+    gstep(TSD_IC(0), TSD_IC(2), TSD_IC(0), TSD_IC(0), TSD_IC(-1), TSD_IC(F_SYNC), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 0 * TILE_FULL), TSD_IC(15));
     gstep(TSD_IC(2), TSD_IC(2), TSD_IC(1), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 1 * TILE_FULL), TSD_IC(15));
     gstep(TSD_IC(2), TSD_IC(2), TSD_IC(2), TSD_IC(0), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 2 * TILE_FULL), TSD_IC(15));
     gstep(TSD_IC(2), TSD_IC(2), TSD_IC(3), TSD_IC(1), TSD_IC(-1), TSD_IC(0), TSD_IC(2), TSD_IC(FFN_CHUNK_BYTES + 3 * TILE_FULL), TSD_IC(15));
