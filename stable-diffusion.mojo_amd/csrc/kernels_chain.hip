@@ -38,7 +38,7 @@
 #define TSD_CHAIN_ABL 0
 #endif
 #ifndef TSD_CHAIN_ARES
-#define TSD_CHAIN_ARES 5  // GEMM-1 k-tiles whose A fragments stay in registers through the feed-forward (0 = none)
+#define TSD_CHAIN_ARES 0  // GEMM-1 k-tiles whose A fragments stay in registers through the feed-forward (0 = none)
 #endif
 #ifndef TSD_CHAIN_PIPE
 #define TSD_CHAIN_PIPE 1  // 0 = the round-2 per-chunk GEGLU loop (A/B builds)
@@ -89,8 +89,12 @@ constexpr int HEAD_TILES = 40;                                    // conv_in (10
 constexpr int HEAD_STREAM_BYTES = HEAD_TILES * TILE_FULL;
 
 __device__ __forceinline__ float gelu_tanh_c(float x) {  // helpers/utils.mojo:1914 (see kernels_gemm.hip)
-  const float c2 = -2.f * 0.7978845608028654f * 1.4426950408889634f;
-  const float t = __builtin_amdgcn_exp2f(c2 * (x + 0.044715f * x * x * x));
+  // x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): the exponent -2u log2(e) = x * (k1 x^2 + k0) as mul, fma, mul (hipcc kept four
+  // operations for c2 * (x + 0.044715 * x * x * x)); these run next to the MFMAs of the feed-forward pipeline, where every VALU
+  // instruction adds its issue time (profiles/r04_chain_geglu_ablation.txt)
+  const float k0 = -2.f * 0.7978845608028654f * 1.4426950408889634f, k1 = k0 * 0.044715f;
+  const float x2 = x * x;
+  const float t = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x2, k1, k0));
   return x * __builtin_amdgcn_rcpf(1.f + t);
 }
 template <int N>
@@ -571,24 +575,38 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   constexpr int KT_B = 80 * 128, V0_OFF = 5 * KT_B, V1_OFF = V0_OFF + 320 * 128;
   static_assert(V1_OFF + 320 * 32 <= NSLOT * SLOT, "context tiles must fit in the ring region");
   {
+    // 100 pieces of 1 KiB, 25 per wave.  Round 4: the per-lane part of every address is computed ONCE (the K row-block offsets of
+    // this wave's row blocks, one V^T offset per region, masks folded in) and the piece number only moves the scalar offset and the
+    // LDS destination - the round-2 loop recomputed key permutation, row and mask per piece behind wave-uniform branches and
+    // exec-masked selects: 6.8 K ticks of issue for 25 pieces (profiles/r04_chain_ticks_*.txt).
     const rsrc_t rk = make_rsrc(p.Kc + bsmp * p.sK), rv = make_rsrc(p.Vt + bsmp * p.sVt);
     const int nch = (p.T + 7) >> 3;
+    // K: row block rb (8 LDS rows) of every k-tile; this wave's row blocks are rb = wave, wave + 4, wave + 8
 #pragma unroll
-    for (int i = 0; i < 25; i++) {
-      const int j = wave + 4 * i;  // 100 pieces of 1 KiB
-      if (j < 50) {                // K: k-tile j/10, rows (j%10)*8 ..
-        const int kt = j / 10, rho = (j - kt * 10) * 8 + lrow, b = rho >> 4, ii = rho & 15;
+    for (int m = 0; m < 3; m++) {
+      const int rb = wave + 4 * m;  // wave-uniform
+      if (rb < 10) {
+        const int rho = rb * 8 + lrow, b = rho >> 4, ii = rho & 15;
         const int kidx = b < 4 ? 32 * (b >> 1) + 8 * (ii >> 2) + 4 * (b & 1) + (ii & 3) : 64 + ii;
-        blds16(rk, kidx < p.T ? (unsigned)(kidx * p.ldk + cch * 8) * 2 : PAD_OFF, kt * 128,
-               smem + RING_OFF + kt * KT_B + (j - kt * 10) * 1024);
-      } else if (j < 90) {         // V^T keys 0..63: rows (j-50)*8 ..
-        const int row = (j - 50) * 8 + lrow;
-        blds16(rv, cch < nch ? (unsigned)(row * p.ldvt + cch * 8) * 2 : PAD_OFF, 0, smem + RING_OFF + V0_OFF + (j - 50) * 1024);
-      } else {                     // V^T keys 64..79: 32 rows x 32 B per piece
-        const int row = (j - 90) * 32 + (lane >> 1), ch = 8 + (lane & 1);
-        blds16(rv, ch < nch ? (unsigned)(row * p.ldvt + ch * 8) * 2 : PAD_OFF, 0, smem + RING_OFF + V1_OFF + (j - 90) * 1024);
+        const unsigned live = (unsigned)((kidx - p.T) >> 31);  // all ones for a valid key
+        const unsigned koff = (((unsigned)(kidx * p.ldk + cch * 8) * 2) & live) | (PAD_OFF & ~live);
+#pragma unroll
+        for (int kt = 0; kt < 5; kt++) blds16(rk, koff, kt * 128, smem + RING_OFF + kt * KT_B + rb * 1024);
       }
     }
+    // V^T keys 0..63: piece j' = rows 8j' .. 8j'+7 (40 pieces: waves 0, 1 take 8 each, waves 2, 3 twelve); keys 64..79: piece j'' = rows
+    // 32j'' .. (10 pieces: 2, 2, 3, 3) - 15 + 8 + 2 = 10 + 12 + 3 = 25 pieces per wave
+    const unsigned vlive0 = (unsigned)((cch - nch) >> 31), vlive1 = (unsigned)((8 + (lane & 1) - nch) >> 31);
+    const unsigned v0off = (((unsigned)(lrow * p.ldvt + cch * 8) * 2) & vlive0) | (PAD_OFF & ~vlive0);
+    const unsigned v1off = (((unsigned)((lane >> 1) * p.ldvt + (8 + (lane & 1)) * 8) * 2) & vlive1) | (PAD_OFF & ~vlive1);
+    const int v0s = wave < 2 ? wave * 8 : 16 + (wave - 2) * 12, v0n = wave < 2 ? 8 : 12;
+    const int v1s = wave < 2 ? wave * 2 : 4 + (wave - 2) * 3, v1n = wave < 2 ? 2 : 3;
+#pragma unroll
+    for (int q = 0; q < 12; q++)
+      if (q < v0n) blds16(rv, v0off, (unsigned)((v0s + q) * 8 * p.ldvt) * 2, smem + RING_OFF + V0_OFF + (v0s + q) * 1024);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      if (q < v1n) blds16(rv, v1off, (unsigned)((v1s + q) * 32 * p.ldvt) * 2, smem + RING_OFF + V1_OFF + (v1s + q) * 1024);
   }
   {
     const float qs4[4] = {p.qscale, p.qscale, p.qscale, p.qscale};
