@@ -547,12 +547,15 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       blds16(ra, (unsigned)((m0 + row) * p.ld_ao + cch * 8) * 2, kt * 128, smem + A_OFF + kt * A_KT + (j & 7) * 1024);
     }
   }
+  seg_begin(0);
+  // residual 1 and the first bias are needed only after the first GEMM: issued BEHIND the ao tile and the first four weight tiles,
+  // so that GEMM starts as soon as those have landed (its first four tile waits leave these 25 loads in flight) - the 20 row loads
+  // are 8-byte pieces of 16 rows each, slow through the texture-address unit, and used to sit in front of the first tile wait
   load_rows_raw(p.tok, p.ld_tok, raw);
   load_cols(p.bso, bv);
-  seg_begin(0);
   CTS(1);
   // ---- tok2 = ao . Wso^T + b + tok ------------------------------------------------------------------------------------
-  gemm(I0{}, Yes{}, I0{}, acc, A_OFF, 10, No{});
+  gemm(I0{}, Yes{}, I25{}, acc, A_OFF, 10, No{});
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
