@@ -18,11 +18,14 @@
 //   * the 77 context keys / values of the sample (projected once per step) are staged in the ring region; the scores
 //     never leave registers: swapped-operand QK^T leaves each lane with the scores of ONE query row, and the key -> MFMA
 //     row permutation makes the fp16 probabilities the A fragments of the P.V MFMAs without any data movement;
-//   * LayerNorm statistics are an in-lane sum + two lane shuffles + one LDS exchange between the two column waves
-//     (per-wave mean / M2 merged exactly);
+//   * LayerNorm statistics are an in-lane sum + two row swaps (v_permlane16/32_swap) + one LDS exchange between the four
+//     column waves (per-wave mean / M2 merged exactly);
 //   * the output's GroupNorm statistics (for the next residual block) come from the rounded values in registers.
-// MFMA: v_mfma_f32_16x16x32_f16 with swapped operands (D = Wfrag x Afrag^T), 4 waves as 2(M) x 2(N), a wave tile is
-// 32 rows x 160 columns (FM = 2, FN = 10), one wave per SIMD.
+// MFMA: v_mfma_f32_16x16x32_f16 with swapped operands (D = Wfrag x Afrag^T).  Round 4: 4 waves as 1(M) x 4(N) - a wave tile is
+// all 64 rows x 80 columns (FM = 4, FN = 5), one wave per SIMD - and every wave streams ITS OWN quarter of the weight tiles, so
+// the tile loops run without a barrier per tile (DESIGN.md 4.2 "Round 4").  Two things in this file exist because of what the
+// ISA listings showed: pin_here() (hipcc moves side-effect-free arithmetic to its use, whatever sched_barriers it was written
+// between) and the static tile walk of the feed-forward pipeline.
 #include <math.h>
 #include <stdlib.h>
 
