@@ -40,6 +40,9 @@
 #ifndef TSD_CHAIN_ABL
 #define TSD_CHAIN_ABL 0
 #endif
+#ifndef TSD_CHAIN_TILE_BARRIER
+#define TSD_CHAIN_TILE_BARRIER 0  // 1 = a barrier at every tile step (diagnostic: the round-3 cadence)
+#endif
 #ifndef TSD_CHAIN_ARES
 #define TSD_CHAIN_ARES 0  // GEMM-1 k-tiles whose A fragments stay in registers through the feed-forward (0 = none)
 #endif
@@ -243,13 +246,18 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   // (bytes [wn * Q, wn * Q + Q), Q = 5 KiB / 4 KiB - exactly the weight rows its MFMAs read), so a wave's counted vmcnt wait is all it
   // needs before it reads a tile, and a ring slot is only ever rewritten by the wave that read it: the tile loops run WITHOUT a
   // barrier per tile (one barrier where the shared A operand changes hands instead of one per step: 140 -> 20 in the feed-forward).
+  // A wave's region of a ring slot is ALWAYS bytes [wave * 5120, wave * 5120 + 5120), whatever the tile kind: the 4-KiB quarter of a
+  // GEMM-1 tile sits at the same 5-KiB stride (its image in memory stays packed).  With the quarters of the two tile kinds at their
+  // natural offsets (w * 4096 vs w * 5120) a wave's DMA of a GEMM-1 quarter overwrote the tail of its neighbour's quarter of the full
+  // tile that had the slot before - which the neighbour could still be reading, now that nothing holds the waves in step: one
+  // generate() in four came out different (scripts/diag_race3.py; found by tests/test_gpu_models.py's bitwise-repeatability cases).
   auto piece = [&](int off, bool g1, bool live, int slot, int i) {
     const int j = wave * (g1 ? 4 : 5) + i;
     const bool on = live && !(g1 && i >= 4);
 #ifdef TSD_CHAIN_NOPIECE  // ablation build: no DMA instructions at all after the first tiles of segment 1 (timing only)
     if (off >= SEG0_BYTES + 12 * TILE_FULL) return;
 #endif
-    blds16(on ? rw : rdead, lane16, (unsigned)(off + j * 1024), smem + RING_OFF + slot * SLOT + j * 1024);
+    blds16(on ? rw : rdead, lane16, (unsigned)(off + j * 1024), smem + RING_OFF + slot * SLOT + wave * 5120 + i * 1024);
   };
   int gt = 0, sl = 0;  // tile counter within the segment ; ring slot of tile gt
   auto seg_begin = [&](int seg) {
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
           default: if (EXTRA > 0 && kt < 4) wait_vm<15 + EXTRA>(); else wait_vm<15>(); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile gt-1 are complete: its slot may be refilled
-        if (!have_prev) __builtin_amdgcn_s_barrier();        // stage start: the A operand every wave wrote a part of is complete
+        if (TSD_CHAIN_TILE_BARRIER & 4) __builtin_amdgcn_s_sleep(1);
+        if (!have_prev || (TSD_CHAIN_TILE_BARRIER & 1)) __builtin_amdgcn_s_barrier();  // stage start: the A operand every wave wrote a part of is complete
         asm volatile("" ::: "memory");
         sA = smem + a_base + (kt >> 1) * A_KT + a_rd + ((((kt & 1) * 4 + g) ^ key) << 4);
         sW = smem + RING_OFF + sl * SLOT + wn * 5120 + w_rd;
@@ -820,10 +829,11 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile gt-1 (and any activation-tile writes) are complete
         // barriers only where the shared activation tile changes hands: before it is rewritten (F_WRITE steps: every wave has finished
         // the previous chunk's GEMM-2 reads) and before its first GEMM-2 read (F_SYNC: every wave's part is written)
-        if constexpr ((FLAGS & (F_WRITE | F_SYNC)) != 0 && !(TSD_CHAIN_ABL & 1)) __builtin_amdgcn_s_barrier();
+        if constexpr ((TSD_CHAIN_TILE_BARRIER & 4) != 0) __builtin_amdgcn_s_sleep(1);
+        if constexpr (((FLAGS & (F_WRITE | F_SYNC)) != 0 || (TSD_CHAIN_TILE_BARRIER & 2)) && !(TSD_CHAIN_ABL & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         sA = smem + (CK == 1 ? A_OFF : ACT_OFF) + (KC >> 1) * A_KT + a_rd + ((((KC & 1) * 4 + g) ^ key) << 4);
-        sW = smem + RING_OFF + sl * SLOT + wn * (FNc == 5 ? 5120 : 4096) + w_rd;
+        sW = smem + RING_OFF + sl * SLOT + wn * 5120 + w_rd;
         s4 = sl == 0 ? 4 : sl - 1;
       }
       const int off = jb + LOFF;
