@@ -384,17 +384,21 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   };
   // LDS byte offset, inside a swizzled [k-tile][64 rows][128 B] A-operand tile, of the 8-B piece holding columns col .. col+3 of `row`
   auto a_piece = [&](int row, int col) { return (col >> 6) * A_KT + row * 128 + ((((col >> 3) & 7) ^ (row & 7)) << 4) + (col & 4) * 2; };
+  // this lane's five 8-byte pieces of fragment row 0 in the A tile: fragment row a is 16 rows = 2048 bytes further on and has the same
+  // swizzle key, so a store is base + immediate (computed per store, the swizzle arithmetic was a tenth of a LayerNorm's instructions)
+  int apo[5];
+#pragma unroll
+  for (int b = 0; b < 5; b++) apo[b] = A_OFF + a_piece(rsel, cbase + b * 4);
   // write fp16((v - sub) * mul) into the A tile (swizzled A-operand layout)
   auto store_a_tile = [&](const f4 (&v)[4][5], const float (&mul)[4], const float (&sub)[4]) {
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-      const int row = a * 16 + rsel;
 #pragma unroll
       for (int b = 0; b < 5; b++) {
         h4 o;
 #pragma unroll
         for (int r = 0; r < 4; r++) o[r] = (half_t)((v[a][b][r] - sub[a]) * mul[a]);
-        *(h4*)(smem + A_OFF + a_piece(row, cbase + b * 4)) = o;
+        *(h4*)(smem + apo[b] + a * 2048) = o;
       }
     }
   };
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
           const int grp = (b * 4 + r) / 10;
           o[r] = (half_t)(((float)raw[a][b][r] - gst[grp][0]) * gst[grp][1]);
         }
-        *(h4*)(smem + A_OFF + a_piece(row, cbase + b * 4)) = o;
+        *(h4*)(smem + apo[b] + a * 2048) = o;
       }
     }
     CTS(1);
