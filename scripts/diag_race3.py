@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "stable-diffusion.mojo_amd"))
 import tsd
 from tsd import rng
 SEED = 1234
-B, L = 8, 64
+B, L = int(os.environ.get("B", 8)), 64
 d = tsd.Diffusion(seed=SEED); dec = tsd.Decoder(seed=SEED); enc = tsd.Encoder(seed=SEED)
 ctx = rng.normal(SEED, 761, B * 77 * 768).reshape(B, 77, 768)
 image = rng.uniform(SEED, 761, B * 3 * 512 * 512, 1.0).reshape(B, 3, 512, 512) * 127.5 + 127.5
