@@ -246,3 +246,19 @@ def test_halo_x_conv_order_matches_plain_tiles(gpu_ctx, B, H, Cin, N, cfg, ref):
     assert r.value > 0.5 and d.value <= (0.0 if Cin == 64 else 2e-3 * r.value), (d.value, r.value)
     # an ineligible problem (stride 2) must be refused, not mis-addressed
     assert lib().tsd_debug_gemm_check(gpu_ctx.h, 1, B, H, H, Cin, N, 2, 0, cfg, ref, C.byref(d), C.byref(r)) != 0
+
+
+@pytest.mark.parametrize("T", [1, 5, 63, 64, 65, 80])
+def test_fused_attention_block_context_lengths(gpu_ctx, tsd_mod, T):
+    """`Unet_Attention_Block` at C = 320 (the fused head / tail kernels) for context lengths around the tail's key-fragment
+    boundaries: T < 64 masks whole key fragments, T = 64 leaves the fifth fragment empty, 65..80 fill it partly / fully
+    (helpers/attention.mojo:105-115: softmax over the T context keys; the row sum comes from a ones row in the P.V MFMAs)."""
+    from cases import _attn_params
+    from oracle import models
+    from util import TOL_BLOCK, TOL_BLOCK_MAX, randn
+    nh, ne, H = 8, 40, 16
+    C = nh * ne
+    i = dict(x=randn(60, C, H, H), c=randn(61 + T, T, 768), P=_attn_params("a", C, 70))
+    ref = np.asarray(models.unet_attention_block(i["P"], "a", i["x"], i["c"], nh, ne), np.float32)
+    y = np.asarray(CASES["unet_attn_8x40"].device(tsd_mod, i), np.float32)
+    assert_close(y, ref, TOL_BLOCK, TOL_BLOCK_MAX, what=f"unet_attn_8x40 with {T} context tokens")
