@@ -31,7 +31,8 @@ for lo, hi, tag in (((0, 256, "round 1 (blocks 0..255)"), (256, 512, "round 2 (b
         dlt = blk[:, i + 1] - blk[:, i]
         print(f"  {nm:22s} med {int(np.median(dlt)):8d}  min {int(dlt.min()):8d}  max {int(dlt.max()):8d}")
     print(f"  {'total':22s} med {int(np.median(blk[:, 9] - blk[:, 0])):8d}")
-    for nm, i, j in (("FFN chunk 5: gemm1", 10, 11), ("FFN chunk 5: act epi", 11, 12), ("FFN chunk 5: gemm2", 12, 13)):
+    # marks 10..13 sit inside the tail's cross attention (round 4): after the post-q barrier | staging issued, q stored | context landed | head 0 done
+    for nm, i, j in (("xattn: staging + q", 10, 11), ("xattn: landing wait", 11, 12), ("xattn: head 0", 12, 13)):
         dlt = blk[:, j] - blk[:, i]
         print(f"  {nm:22s} med {int(np.median(dlt)):8d}  min {int(dlt.min()):8d}  max {int(dlt.max()):8d}")
 dur = (a[:nblk, 15] - a[:nblk, 14]) * 0.01

@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   CTS(4);
   wait_vm<0>();   // the dead tail of segment 0 has landed: the ring region is free for the context keys / values
   lds_barrier();  // every wave is done reading LN(tok2) and the last weight tile
+  CTS(10);
   // ---- cross attention over the sample's T context keys (helpers/attention.mojo:105-115) ------------------------------
   // Ring region: K tile 5 k-tiles x [80 key rows][128 B] (weight-operand layout) | V^T keys 0..63 [320 rows][128 B] |
   // V^T keys 64..79 [320 rows][32 B].  K row b*16 + ii holds key 32*(b>>1) + 8*(ii>>2) + 4*(b&1) + (ii&3) for b < 4
@@ -632,8 +633,10 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     store_a_tile(acc, qs4, zero4);  // q -> A tile while the context tiles fly
   }
   load_cols(p.bco, bv);
+  CTS(11);
   wait_vm<5>();   // the context tiles have landed (the 5 bias loads are younger)
   lds_barrier();  // q tile and context tiles visible
+  CTS(12);
   // per wave: all 64 rows, heads 2*wn and 2*wn+1 (its own 80 columns of q: no other wave reads or writes them)
   const bool t_ge64 = p.T >= 64;  // wave-uniform: only key fragment 4 (keys 64 + 4g + r) can hold a key >= T
   f4 mk4;
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
     float rinv[4];
 #pragma unroll
     for (int a = 0; a < 4; a++) rinv[a] = 1.f / rows_sum(g == 2 ? oc[a][2][0] : 0.f);
+    if (hh == 0) CTS(13);
     // The head's output overwrites the head's q columns in the A tile.  Columns h*40 .. h*40+39 are read (as q) and written by
     // THIS wave only, and its QK^T for this head is done, so no barrier is needed.  lane (g, r) of fragment b holds channel
     // h*40 + b*16 + 4g + r.
