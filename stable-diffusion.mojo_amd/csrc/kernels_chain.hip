@@ -46,9 +46,6 @@
 #ifndef TSD_CHAIN_ARES
 #define TSD_CHAIN_ARES 0  // GEMM-1 k-tiles whose A fragments stay in registers through the feed-forward (0 = none)
 #endif
-#ifndef TSD_CHAIN_PIPE
-#define TSD_CHAIN_PIPE 1  // 0 = the round-2 per-chunk GEGLU loop (A/B builds)
-#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
