@@ -9,7 +9,7 @@ typedef int rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, unsigned soff, void* lds) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0), (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
-__global__ __launch_bounds__(256, 1) void k(const char* src, int pattern, int n, unsigned long long* out, int mode) {
+__global__ __launch_bounds__(256, 1) void k(const char* src, int pattern, int n, unsigned long long* out, int mode, int stream_kb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned voff;
@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, int pattern, int n,
   for (int it = 0; it < n; it += 8) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + wave * 16384 + u * 1024), 16, voff, (unsigned)(u * (pattern == 0 ? 1024 : 128)), 0, 0);
+      // stream_kb = 0: the wave re-reads its 16 KiB window (vL1D hits after the first pass); > 0: every instruction reads new lines of a
+      // stream_kb-KiB region shared by the workgroups of an XCD-sized group (L2 hits, like weight tiles every CU pulls)
+      const unsigned soff = stream_kb ? (unsigned)(((it + u) * 4 + wave) * 1024) % (unsigned)(stream_kb * 1024) : (unsigned)(u * (pattern == 0 ? 1024 : 128));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + wave * 16384 + u * 1024), 16, stream_kb ? (unsigned)(lane * 16) : voff, soff, 0, 0);
       if (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // at most 4 in flight: latency-bound cadence
     }
   }
@@ -43,10 +46,22 @@ int main() {
   for (int mode = 0; mode < 2; mode++)
     for (int p = 0; p < 5; p++) {
       std::vector<unsigned long long> h(nb * 4 * 2);
-      for (int rep = 0; rep < 3; rep++) { hipLaunchKernelGGL(k, dim3(nb), dim3(256), 65536, 0, src, p, n, out, mode); hipDeviceSynchronize(); }
+      for (int rep = 0; rep < 3; rep++) { hipLaunchKernelGGL(k, dim3(nb), dim3(256), 65536, 0, src, p, n, out, mode, 0); hipDeviceSynchronize(); }
       hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
       double a = 0, b = 0; for (int i = 0; i < nb * 4; i++) { a += h[2 * i]; b += h[2 * i + 1]; }
       printf("%s | %-28s: issue %.1f ticks per instruction, issue + drain %.1f (256 CUs x 4 waves, %d instructions each)\n", mode ? "<=4 in flight" : "back to back ", names[p], a / (nb * 4) / n, b / (nb * 4) / n, n);
+    }
+  // the stream every CU pulls through its L2 (lane-linear 1-KiB pieces of a shared region that does not fit the 32 KiB vL1D): what a weight
+  // stream can sustain per CU with the whole chip streaming, by instructions allowed in flight per wave
+  for (int skb : {2048, 16384})
+    for (int mode = 0; mode < 2; mode++) {
+      std::vector<unsigned long long> h(nb * 4 * 2);
+      const int n2 = 2048;
+      for (int rep = 0; rep < 3; rep++) { hipLaunchKernelGGL(k, dim3(nb), dim3(256), 65536, 0, src, 0, n2, out, mode, skb); hipDeviceSynchronize(); }
+      hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
+      double b = 0; for (int i = 0; i < nb * 4; i++) b += h[2 * i + 1];
+      const double ticks = b / (nb * 4) / n2;
+      printf("shared %5d-KiB stream, %s: %.1f ticks per 1-KiB instruction per wave = %.1f B/clk per CU (4 waves)\n", skb, mode ? "<= 4 in flight per wave " : "queue-deep (up to 63)   ", ticks, 4096.0 / ticks);
     }
   return 0;
 }
