@@ -144,6 +144,29 @@ def pmc_traffic_per_gemm_launch():
     return None, None
 
 
+def pmc_l2_to_cu_bytes_per_step():
+    """(bytes a UNet step pulls from the L2 into the CUs, source file) from the committed vL1D counter pass (rocprofv3 --pmc
+    TCP_TCC_READ_REQ, scripts/gpu_pmc_tcp.sh -> profiles/rNN_pmc_tcp.txt; 128 B per request, the probe kernel excluded; steps in
+    the pass = dispatches of the fused tail / 3).  Not measured by this run - the JSON line names the file."""
+    import re
+    for name in ("r04_pmc_tcp.txt", "r03_pmc_tcp.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            total, tail = 0.0, 0.0
+            for line in open(path).read().splitlines()[2:]:
+                m = re.match(r"^(.*?)\s{2,}(\d+)\s+\d+\s+\d+\s+(\d+)\s+\d+", line)
+                if not m or "mfma_probe" in m.group(1):
+                    continue
+                total += float(m.group(2)) * float(m.group(3)) * 128.0
+                if m.group(1).strip().endswith("attn_chain_kernel<0>"):
+                    tail = float(m.group(2))
+            if total and tail:
+                return total / (tail / 3.0), "profiles/" + name
+        except OSError:
+            continue
+    return None, None
+
+
 def cpu_baseline(L, T):
     """The oracle (numpy restatement of the reference's algorithm - 'port') timed on this box's host cores on a
     bounded sample: ONE sample-step (1/8 of a batch-8 step: one Diffusion.forward + DDPM update at L=64)."""
@@ -329,9 +352,19 @@ def main():
         gemm_gf_step = (total_gf - attn_gf) * B - chain_lin_gf
         achieved = (gemm_gf_step / 1e3) / (gemm_ms / 1e3) if gemm_ms > 0 else 0.0  # TFLOP/s
         traffic, traffic_src = pmc_traffic_per_gemm_launch()
+        l2b, l2src = pmc_l2_to_cu_bytes_per_step()
+        if B != 8 or L != 64:
+            l2b = None  # the counter pass is of the headline configuration
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<...> (dense + conv3x3 implicit GEMM)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+                    # the path the GEMM-class K loops and the fused tail actually run on: L2 -> CU bytes per step from the
+                    # committed TCP counter pass against the ceiling scripts/micro/dma_issue.hip measures with the whole chip streaming
+                    "l2_to_cu": None if l2b is None else {
+                        "bytes_per_step": int(l2b), "ceiling_TBps": 15.0, "floor_ms_per_step": round(l2b / 15.0e12 * 1e3, 3),
+                        "frac_of_step": round(l2b / 15.0e12 * 1e3 / (1e3 * dt / K), 4),
+                        "source": f"{l2src} (TCP_TCC_READ_REQ x 128 B, batch 8; committed file, NOT measured by this run); ceiling: "
+                                  "profiles/r04_micro_dma_issue.txt (28 B/clk per CU, 256 CUs)"},
                     "traffic_source": None if traffic is None else f"{traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                       "passes over this same command, scripts/gpu_pmc_bench.sh; committed file, NOT measured by this run)",
                     "launches_per_step": gemm_launches, "avg_launch_us": round(1e3 * gemm_ms / max(1, gemm_launches), 2),
