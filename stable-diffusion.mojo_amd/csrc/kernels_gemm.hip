@@ -1226,7 +1226,12 @@ static int splitk_plan(const TsdOptions& o, int M, int N, int K, int batch, int 
   //  * rps <= 1024 with N * rps <= 320 * 1024 (the 64x64 -> 32x32 downsampling conv, N = 320, K = 2880: 128 tiles): 2 slices.
   const int wide = o.splitk_wide;
   const bool mid = wide && rps > 256 && rps <= 1024 && (long long)N * rps <= 320LL * 1024 && K >= 2880;
-  if (!on || batch != 1 || N <= 16 || rps <= 0 || (rps > 256 && !mid)) return 1;
+  // Round 4 (TSD_GEMM_SK256): 256x160 tiles (the staggered loader-wave configuration 51) for split launches, with twice the slices so
+  // that the grid stays the same: a K tile then pulls 52 KB from the L2 for twice the products of a 128x160 tile's 36 KB (98 instead of
+  // 71 flop per L2 byte; the K loops of these layers run on the L2 -> CU path).  Bit 0: the 16x16-level layers that split
+  // already; bit 1: the 32x32-level 640-wide convolutions (K >= 5760: 256 tiles of 128x160 today, no split).  Keyed on the layer only.
+  const bool mid256 = (o.sk256 & 2) && rps == 1024 && N == 640 && K >= 5760;
+  if (!on || batch != 1 || N <= 16 || rps <= 0 || (rps > 256 && !mid && !mid256)) return 1;
   const bool n160 = (N % 160 == 0);
   const int BN = n160 ? 160 : 128;
   int ways = 1, BM = 128;
@@ -1246,6 +1251,13 @@ static int splitk_plan(const TsdOptions& o, int M, int N, int K, int batch, int 
     if (mid) ways = 2;
     const int sk128 = o.sk_cfg;  // 45: the same tile with loader waves
     if (cfg) *cfg = n160 ? sk128 : 8;
+    const int tn = ceil_div(N, BN);
+    const bool xcd256 = tn % 8 == 0 || (wide && rps % 256 == 0 && (tn * (rps / 256)) % 8 == 0);  // a tile's slices stay on one XCD
+    if (n160 && xcd256 && ((mid256 && !mid) || ((o.sk256 & 1) && rps == 256 && ways >= 2 && ways <= 4))) {
+      ways = mid256 ? 2 : ways * 2;
+      BM = 256;
+      if (cfg) *cfg = 51;
+    }
   }
   // Eligibility looks at N only (8 | N-tiles keeps a tile's slices on one XCD for any M): a condition on the tile
   // count would make the split - and with it the fp32 summation tree - depend on the batch.  The two M-dependent
@@ -1546,7 +1558,7 @@ int launch_gemm(tsd_ctx* ctx, const GemmArgs& a) {
   const int ways = ctx->opt.force_cfg < 0 ? splitk_plan(ctx->opt, a.M, a.N, a.K, a.batch, a.rows_per_sample_hint, &sk_cfg) : 1;
   const bool splitk = ways > 1;
   if (splitk) {
-    const int BN = (a.N % 160 == 0) ? 160 : 128, BM = (sk_cfg == 7 || sk_cfg == 10 || sk_cfg == 6 || sk_cfg == 9) ? 64 : 128;
+    const int BN = (a.N % 160 == 0) ? 160 : 128, BM = (sk_cfg == 7 || sk_cfg == 10 || sk_cfg == 6 || sk_cfg == 9) ? 64 : (sk_cfg == 51 ? 256 : 128);
     sk_ws = arena_alloc<float>(ctx, (int64_t)(ways - 1) * ceil_div(a.M, BM) * ceil_div(a.N, BN) * BM * BN);
     if (!sk_ws) TSD_FAIL(TSD_E_ALLOC, "gemm: split-K workspace exhausted");
   }

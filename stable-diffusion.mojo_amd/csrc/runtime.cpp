@@ -38,6 +38,7 @@ void options_from_env(TsdOptions& o) {
   o.splitk_ring4 = env_int("TSD_GEMM_SPLITK_RING4", o.splitk_ring4);
   o.splitk_big = env_int("TSD_GEMM_SPLITK_BIG", o.splitk_big);
   o.sk_cfg = env_int("TSD_GEMM_SK_CFG", o.sk_cfg);
+  o.sk256 = env_int("TSD_GEMM_SK256", o.sk256);
   o.thin_cfg = env_int("TSD_GEMM_THIN_CFG", o.thin_cfg);
   o.tune = env_int("TSD_GEMM_TUNE", o.tune);
   if (const char* ov = getenv("TSD_GEMM_CFG_OVERRIDE")) { strncpy(o.cfg_override, ov, sizeof(o.cfg_override) - 1); o.cfg_override[sizeof(o.cfg_override) - 1] = 0; }
