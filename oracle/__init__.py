@@ -13,5 +13,9 @@ named after wherever the Mojo body is undefined.  It is
 instead against ``torch.nn.functional`` for the ops whose formula equals PyTorch's
 (tests/test_oracle_pins.py), against hand-derived values for the formulas that differ
 (GroupNorm ``sigma+eps``, tanh-GELU), and against committed fixtures in ``tests/golden``.
+
+``oracle/cref/cref.c`` (+ ``oracle/cref.py``) states the same ops a second time in C, as the reference's own loop nests
+with OpenMP where the reference calls ``parallelize`` (``cpu_ref``); the two statements are
+held against each other in tests/test_cref_cpu.py, and the C one is what bench.py's ``cpu_baseline`` times.
 """
 from . import rng, ops, spec, models, sampler  # noqa: F401

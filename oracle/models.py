@@ -3,11 +3,24 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Single-sample functions in the reference's CHW
 layout; `P` is a {name: array} dict keyed as in oracle/spec.py, `prefix` selects the sub-module.
 """
+import contextlib
+
 import numpy as np
 
 from . import ops
 from .ops import DEFAULT
 from .spec import UNET_LAYERS, DECODER_LAYERS, ENCODER_LAYERS, FULL_UNET_STEPS
+
+
+@contextlib.contextmanager
+def using_ops(backend):
+    """Run the graphs below on another statement of the ops (oracle.cref.backend(): the reference's loop nests in C)."""
+    global ops
+    saved, ops = ops, backend
+    try:
+        yield
+    finally:
+        ops = saved
 
 
 def _conv(P, name, x, k_pad, stride=(1, 1), pad_hw=None):

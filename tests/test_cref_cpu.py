@@ -1,0 +1,129 @@
+"""The C restatement of the reference's loops (oracle/cref/cref.c) against the numpy oracle and the committed fixtures.
+
+Two independent statements of the same algorithm - numpy (im2col + BLAS, pairwise sums) and the reference's own loop
+nests in C (fp32 running sums in the reference's order) - have to agree to fp32 rounding on every op, on every parity
+case of tests/cases.py and on whole graphs.  CPU only; nothing here touches the product."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import cref, models, ops, rng, spec
+from test_golden import G, _sub
+
+CB = cref.backend()
+R = np.random.default_rng(20260930)
+
+
+def f32(*shape, scale=1.0, shift=0.0):
+    return (R.standard_normal(shape) * scale + shift).astype(np.float32)
+
+
+def close(a, b, tol=2e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
+def test_library_is_the_c_file_and_exports_the_ops():
+    L = cref.lib()
+    assert L.cref_version() == 1 and cref.threads() >= 1
+    src = open(os.path.join(os.path.dirname(cref.__file__), "cref", "cref.c")).read()
+    for name in cref._SIG:
+        assert "API" in src and name + "(" in src and hasattr(L, name)
+
+
+@pytest.mark.parametrize("kw", [dict(padding=(1, 1)), dict(padding=(1, 1), stride=(2, 2)), dict(padding=(0, 0)),
+                                dict(padding=(0, 0), stride=(2, 2), pad_hw=((0, 1), (0, 1))), dict(padding=(2, 1), stride=(1, 2))])
+def test_conv2d(kw):
+    x, w, b = f32(24, 13, 9), f32(20, 24, 3, 3, scale=0.1), f32(20)
+    close(CB.conv2d(x, w, b, **kw), ops.conv2d(x, w, b, **kw))
+    close(CB.conv2d(x, w[:, :16], None, **kw), ops.conv2d(x, w[:, :16], None, **kw))   # first 16 channels only (App.A D11)
+    w1 = f32(7, 24, 1, 1)
+    close(CB.conv2d(x, w1, None), ops.conv2d(x, w1, None))
+
+
+def test_pad_and_upsample_are_exact():
+    x = f32(5, 7, 6)
+    assert np.array_equal(CB.pad(x, (0, 1), (2, 0)), ops.pad(x, (0, 1), (2, 0)))
+    assert np.array_equal(CB.upsample_nearest2x(x), ops.upsample_nearest2x(x))
+
+
+def test_norms():
+    x = f32(64, 8, 8, scale=3.0, shift=1.0)
+    close(CB.group_norm(x, 32), ops.group_norm(x, 32))
+    close(CB.group_norm(x, 16, 32), ops.group_norm(x, 16, 32))        # fewer channels than the tensor holds
+    close(CB.group_norm(x, 64, eps=1e-6), ops.group_norm(x, 64, eps=1e-6))
+    t = f32(50, 320, scale=2.0, shift=-0.5)
+    close(CB.layer_norm(t), ops.layer_norm(t))
+    const = np.full((8, 4, 4), 2.5, np.float32)                        # sigma = 0: (x - mu) / eps = 0, not NaN
+    assert np.array_equal(CB.group_norm(const, 2), np.zeros_like(const))
+
+
+def test_elementwise_and_time_embedding():
+    t = f32(50, 33, scale=4.0)
+    close(CB.silu(t), ops.silu(t), 1e-6)
+    close(CB.gelu_tanh(t), ops.gelu_tanh(t), 1e-6)
+    close(CB.quick_gelu(t), ops.quick_gelu(t), 1e-6)
+    for step in (0.0, 1.0, 500.0, 980.0):
+        close(CB.time_embedding(step), ops.time_embedding(step), 1e-6)
+
+
+def test_linear_matmul_softmax():
+    x, w, b = f32(50, 320), f32(100, 320, scale=0.05), f32(100)
+    close(CB.linear(x, w, b), ops.linear(x, w, b))
+    close(CB.linear(x[:1], w, None), ops.linear(x[:1], w, None))       # M = 1 (the time path)
+    a3, b3, b1 = f32(4, 5, 6), f32(4, 6, 7), f32(1, 6, 7)
+    close(CB.matmul(a3, b3), ops.matmul(a3, b3))
+    close(CB.matmul(a3, b1), ops.matmul(a3, b1))                       # B broadcast when B.dim0 == 1 (helpers/utils.mojo:1549-1569)
+    s = f32(3, 9, 77, scale=6.0)
+    close(CB.softmax_lastdim(s), ops.softmax_lastdim(s), 1e-6)
+    close(CB.softmax_lastdim(s).sum(-1), np.ones((3, 9)), 1e-6)
+
+
+@pytest.mark.parametrize("H,D,Tq,Tk,causal", [(8, 320, 50, 50, False), (8, 640, 33, 77, False), (1, 64, 40, 40, False),
+                                              (12, 768, 20, 20, True), (8, 320, 7, 1, False)])
+def test_attention(H, D, Tq, Tk, causal):
+    q, k, v = f32(Tq, D), f32(Tk, D), f32(Tk, D)
+    close(CB.attention_core(q, k, v, H, causal), ops.attention_core(q, k, v, H, causal))
+    w_in, w_out, b_out = f32(3 * D, D, scale=D ** -0.5), f32(D, D, scale=D ** -0.5), f32(D)
+    if Tq == Tk:
+        close(CB.self_attention(q, H, w_in, None, w_out, b_out, causal), ops.self_attention(q, H, w_in, None, w_out, b_out, causal))
+    ctx = f32(Tk, 96)
+    wk = f32(D, 96, scale=0.1)
+    args = (w_out, None, wk, None, wk[::-1], None, w_out.T.copy(), b_out)
+    close(CB.cross_attention(q, ctx, H, *args), ops.cross_attention(q, ctx, H, *args))
+
+
+@pytest.mark.parametrize("name", cases.GOLDEN)
+def test_c_restatement_reproduces_golden(name, monkeypatch):
+    """Every committed fixture, recomputed with the C loops in place of the numpy ops."""
+    c = cases.CASES[name]
+    monkeypatch.setattr(cases, "ops", CB)
+    with models.using_ops(CB):
+        y = np.asarray(c.oracle(c.build()), dtype=np.float32)
+    ref = G[name]
+    got = _sub(y, name)
+    assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+    m = G[name + "__meta"]
+    assert abs((y.astype(np.float64) ** 2).sum() - m[3]) <= 1e-4 * max(1.0, m[3])
+
+
+def test_whole_unet_and_decoder_graphs():
+    seed, L = 77, 8
+    P = spec.init_params("diffusion", seed, only_used=True)
+    lat = rng.normal(seed, 1, 4 * L * L).reshape(4, L, L)
+    ctx = rng.normal(seed, 2, 77 * 768).reshape(77, 768)
+    a = models.diffusion(P, lat, ctx, ops.time_embedding(321.0))
+    with models.using_ops(CB):
+        b = models.diffusion(P, lat, ctx, CB.time_embedding(321.0))
+    assert models.ops is ops                                           # the switch is scoped
+    e = np.linalg.norm(a - b) / np.linalg.norm(a)
+    assert e < 2e-5, e
+    Pd = spec.init_params("decoder", seed, only_used=True)
+    a = models.decoder(Pd, lat[:, :4, :4])
+    with models.using_ops(CB):
+        b = models.decoder(Pd, lat[:, :4, :4])
+    e = np.linalg.norm(a - b) / np.linalg.norm(a)
+    assert e < 2e-5, e
