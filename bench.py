@@ -171,7 +171,7 @@ def cpu_baseline(L, T):
     """The CPU restatements of the reference's algorithm ('port') timed on this box's host cores on a bounded sample: ONE
     sample-step (1/8 of a batch-8 step: one Diffusion.forward + DDPM update at L=64).  Two statements are timed: the
     reference's own loop nests in C with OpenMP where the reference calls `parallelize` (oracle/cref/cref.c - the shape of the
-    reference's CPU path, and the reported value) and the numpy oracle (im2col + BLAS).  Returns (t_c, threads_c, t_numpy)."""
+    reference's CPU path, and the reported value) and the numpy oracle (im2col + BLAS).  Returns (t_c per sample-step, threads, t_numpy, repetitions of the C leg)."""
     from oracle import cref, models as omodels, ops as oops, rng as orng, sampler as osampler, spec as ospec
     P = ospec.init_params("diffusion", SEED, only_used=True)
     lat = orng.normal(SEED, 2, 4 * L * L).reshape(4, L, L)
@@ -189,11 +189,22 @@ def cpu_baseline(L, T):
         return dt, x
 
     cb = cref.backend()
+    n_thr = cref.set_threads(cref.threads_available())  # the CPUs this process may run on (cgroup quota), not the host's count
+    t_c, reps = 0.0, 0
     with omodels.using_ops(cb):
-        t_c, x_c = sample_step(cb)
-    t_np, x_np = sample_step(oops)
+        while reps < 8 and t_c < 10.0:  # bounded sample: at most one batch worth of sample-steps, about 10 s of CPU work
+            dt, x_c = sample_step(cb)
+            t_c += dt
+            reps += 1
+    t_c /= reps
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=n_thr):
+            t_np, x_np = sample_step(oops)
+    except ImportError:
+        t_np, x_np = sample_step(oops)
     assert np.linalg.norm(x_c - x_np) <= 1e-4 * np.linalg.norm(x_np)  # the two statements agree on the timed sample
-    return t_c, cref.threads(), t_np
+    return t_c, n_thr, t_np, reps
 
 
 def main():
@@ -490,18 +501,13 @@ def main():
         images_per_s = (world * B) / ((n_sched * ms_per_step + (dec_ms or 0.0)) / 1e3)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 figure
-            t_sample, c_threads, t_numpy = cpu_baseline(L, T)
-            try:  # threads the numpy oracle's BLAS actually runs on (its pool may be smaller than the host's core count)
-                from threadpoolctl import threadpool_info
-                blas_threads = max([p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"] or [os.cpu_count()])
-            except Exception:
-                blas_threads = os.cpu_count()
+            t_sample, c_threads, t_numpy, c_reps = cpu_baseline(L, T)
             cpu = {"value": round(1.0 / (B * t_sample), 6), "unit": "steps/s", "cores": c_threads, "kind": "port",
-                   "host_cores": os.cpu_count(),
+                   "host_cores": os.cpu_count(),  # cores = the CPU quota of this process (cgroup cpu.max), the OpenMP team's size
                    "sample": f"one sample-step (1/{B} of a batch-{B} step: Diffusion.forward + DDPM update, L={L}, T={T}) "
                              f"of oracle/cref/cref.c (the reference's loop nests in C, OpenMP over output channels / rows, "
-                             f"fp32, {c_threads} threads) took {t_sample:.1f} s; value = 1/({B} x that)",
-                   "numpy_oracle": {"value": round(1.0 / (B * t_numpy), 6), "cores": blas_threads,
+                             f"fp32, {c_threads} threads) took {t_sample:.2f} s (mean of {c_reps}); value = 1/({B} x that)",
+                   "numpy_oracle": {"value": round(1.0 / (B * t_numpy), 6), "cores": c_threads,
                                     "sample": f"the same sample-step on the numpy oracle (im2col + BLAS) took {t_numpy:.1f} s"}}
         whole_frac = steps_per_s / world * B * total_gf / 1e3 / PEAK_FP16_TFLOPS
         line = {

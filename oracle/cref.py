@@ -25,6 +25,7 @@ _i, _l, _fl = ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIG = {
     "cref_version": (ctypes.c_int, []),
     "cref_threads": (ctypes.c_int, []),
+    "cref_set_threads": (None, [ctypes.c_int]),
     "cref_silu": (None, [_f, _f, _l]),
     "cref_gelu_tanh": (None, [_f, _f, _l]),
     "cref_quick_gelu": (None, [_f, _f, _l]),
@@ -64,6 +65,30 @@ def lib():
 
 def threads():
     return int(lib().cref_threads())
+
+
+def threads_available():
+    """CPUs this process may actually run on: the affinity mask, cut by the cgroup's CPU quota when there is one (a
+    container that sees 256 cores may be allowed far fewer; an OpenMP team larger than that only spins)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_threads(n):
+    lib().cref_set_threads(int(n))
+    return threads()
 
 
 def _a(x):

@@ -33,6 +33,15 @@ API int cref_threads(void) {
 #endif
 }
 
+/* the bench picks the thread count from the host's CPU quota (oracle/cref.py threads_available) */
+API void cref_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* ---- elementwise ------------------------------------------------------------------------------------------------- */
 
 /* SiLU.forward helpers/utils.mojo:1892-1902: x / (1 + exp(-x)) */
