@@ -262,3 +262,35 @@ def test_fused_attention_block_context_lengths(gpu_ctx, tsd_mod, T):
     ref = np.asarray(models.unet_attention_block(i["P"], "a", i["x"], i["c"], nh, ne), np.float32)
     y = np.asarray(CASES["unet_attn_8x40"].device(tsd_mod, i), np.float32)
     assert_close(y, ref, TOL_BLOCK, TOL_BLOCK_MAX, what=f"unet_attn_8x40 with {T} context tokens")
+
+
+@pytest.mark.parametrize("cin,cout,H", [(640, 1280, 16), (640, 640, 32)])
+def test_optin_256_row_splitk_tiles_match_oracle(cin, cout, H, gpu_ctx, tsd_mod, monkeypatch):
+    """`TSD_GEMM_SK256` (off by default, experiments/README.md): the split-K layers of the 16x16 level (bit 0) and the 640-wide
+    convolutions of the 32x32 level (bit 1) on 256-row tiles with twice the K slices.  The option is read when a context is created;
+    a context created with both bits on must still give the reference's residual block, and the default context must be untouched."""
+    from cases import _res_params
+    from oracle import models
+    from tsd._lib import Context
+    from util import TOL_BLOCK, TOL_BLOCK_MAX, randn
+    x, time, P = randn(30, cin, H, H), randn(31, 1, 1280), _res_params("r", cin, cout, 40)
+
+    def run(ctx):
+        r = tsd_mod.Unet_Residual_Block(cin, cout, ctx=ctx)
+        r.layer2.kernel, r.layer2.bias = P["r.layer2.kernel"], P["r.layer2.bias"]
+        r.layer3.weight, r.layer3.bias = P["r.layer3.weight"], P["r.layer3.bias"]
+        r.layer5.kernel, r.layer5.bias = P["r.layer5.kernel"], P["r.layer5.bias"]
+        if cin != cout:
+            r.layer6.kernel, r.layer6.bias = P["r.layer6.kernel"], P["r.layer6.bias"]
+        return np.asarray(r.forward(x, time), np.float32)
+
+    before = run(gpu_ctx)
+    monkeypatch.setenv("TSD_GEMM_SK256", "3")
+    ctx = Context(gpu_ctx.device)
+    monkeypatch.delenv("TSD_GEMM_SK256")
+    y = run(ctx)
+    ref = np.asarray(models.unet_residual_block(P, "r", x, time, cin, cout), np.float32)
+    assert_close(y, ref, TOL_BLOCK, TOL_BLOCK_MAX, what=f"res {cin}->{cout} @{H} with 256-row split-K tiles")
+    assert_close(before, ref, TOL_BLOCK, TOL_BLOCK_MAX, what="default context")
+    assert not np.array_equal(y, before)            # another summation tree really ran
+    assert np.array_equal(run(gpu_ctx), before)     # ... and only in the context that asked for it
