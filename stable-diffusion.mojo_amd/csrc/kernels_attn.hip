@@ -141,43 +141,20 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
       const int ch = ks * 2 + hi;
       if (ch < DCH) qf[qb][ks] = *(const h8*)(qp + ch * 8);
       else qf[qb][ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-      // scale * log2(e) goes into Q once (fp32 multiply, one fp16 rounding), so the MFMA result is already the exponent
-      // and the per-score v_fma_f32 of the softmax disappears
-#pragma unroll
-      for (int e = 0; e < 8; e++) qf[qb][ks][e] = (half_t)((float)qf[qb][ks][e] * p.c);
     }
   }
-
-  // ---- second optimistic reference (round 3): the query's OWN 32-key block ------------------------------------
-  // Trained self-attention is peaked on a token's own neighbourhood; when that is not in key tile 0 a score can exceed tile 0's
-  // row maximum by more than the 20 log2 units the optimistic pass tolerates and the whole workgroup repeats exactly (a 2x
-  // cliff on this kernel).  One extra S^T block per query block (3 MFMAs, K fragments straight from global memory, once per
-  // kernel) gives the row maximum over keys q0+32*qb .. +31 as a second lower bound of the true maximum.  The key set is the
-  // same for the 32- and the 64-query-per-wave variants, so they stay bitwise equal.
-  float mxd[QB];
+  // scale * log2(e) goes into Q once (fp32 multiply, one fp16 rounding), so the MFMA result is already the exponent
+  // and the per-score v_fma_f32 of the softmax disappears.  Applied AFTER tile 0's DMA has been issued (below): the Q round trip
+  // and the first K / V^T round trip then overlap instead of following each other (every launch; the 77-key and 256-key
+  // launches of the lower levels are a handful of such round trips long).
+  auto scale_q = [&]() {
 #pragma unroll
-  for (int qb = 0; qb < QB; qb++) {
-    mxd[qb] = -1.0e30f;
-    if (p.diag) {
-      int krow = q0 + qb * 32 + l31;
-      if (krow >= p.Sk) krow = p.Sk - 1;
-      const half_t* kp = Kb + (long long)krow * p.ldk;
-      f16v sd;
+    for (int qb = 0; qb < QB; qb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) sd[r] = 0.f;
+      for (int ks = 0; ks < KSTEPS; ks++)
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++) {
-        const int ch = ks * 2 + hi;
-        h8 kf = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (ch < DCH) kf = *(const h8*)(kp + ch * 8);
-        sd = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], sd, 0, 0, 0);
-      }
-      float m = sd[0];
-#pragma unroll
-      for (int r = 1; r < 16; r++) m = fmaxf(m, sd[r]);
-      mxd[qb] = fmaxf(m, __shfl_xor(m, 32));
-    }
-  }
+        for (int e = 0; e < 8; e++) qf[qb][ks][e] = (half_t)((float)qf[qb][ks][e] * p.c);
+  };
 
   // ---- per-thread DMA slots -------------------------------------------------------------------
   // Tiles go global -> LDS through buffer descriptors (lds_dma.h): a 32-bit byte offset per DMA instruction, the
@@ -236,6 +213,41 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
     *(h8*)(smem + buf * BUF_BYTES + K_BYTES + R * 128 + pos * 16) = h8{fill, fill, fill, fill, fill, fill, fill, fill};
   }
 
+  // tile 0 of the optimistic pass goes out now (the pad rows above and the DMA'd rows are disjoint), then Q is scaled
+  stage(0, 0);
+  scale_q();
+
+  // ---- second optimistic reference (round 3): the query's OWN 32-key block ------------------------------------
+  // Trained self-attention is peaked on a token's own neighbourhood; when that is not in key tile 0 a score can exceed tile 0's
+  // row maximum by more than the 20 log2 units the optimistic pass tolerates and the whole workgroup repeats exactly (a 2x
+  // cliff on this kernel).  One extra S^T block per query block (3 MFMAs, K fragments straight from global memory, once per
+  // kernel) gives the row maximum over keys q0+32*qb .. +31 as a second lower bound of the true maximum.  The key set is the
+  // same for the 32- and the 64-query-per-wave variants, so they stay bitwise equal.
+  float mxd[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; qb++) {
+    mxd[qb] = -1.0e30f;
+    if (p.diag) {
+      int krow = q0 + qb * 32 + l31;
+      if (krow >= p.Sk) krow = p.Sk - 1;
+      const half_t* kp = Kb + (long long)krow * p.ldk;
+      f16v sd;
+#pragma unroll
+      for (int r = 0; r < 16; r++) sd[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        const int ch = ks * 2 + hi;
+        h8 kf = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ch < DCH) kf = *(const h8*)(kp + ch * 8);
+        sd = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], sd, 0, 0, 0);
+      }
+      float m = sd[0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) m = fmaxf(m, sd[r]);
+      mxd[qb] = fmaxf(m, __shfl_xor(m, 32));
+    }
+  }
+
   // Online softmax with a LAZY reference: the exponent s - ref comes straight out of the QK^T MFMAs (ref enters as their
   // C operand, a 16-register block holding -ref).  Tile 0 sets ref from its exact row maximum (so the sum cannot
   // underflow).  Two passes share the loop below:
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
 #pragma unroll
     for (int r = 0; r < 16; r++) nm[qb][r] = 0.f;
   }
-  stage(0, 0);
+  if (EXACT) stage(0, 0);  // the optimistic pass' tile 0 was issued before Q was scaled
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < ntiles; t++) {
