@@ -22,3 +22,9 @@ for i in range(N):
     h = hashlib.sha1(o.tobytes()).hexdigest()[:10]
     cnt[h] += 1; outs.setdefault(h, (i, o))
 print(f"{mode}: {N} x generate: {len(cnt)} distinct results {dict(cnt)} first seen at {[v[0] for v in outs.values()]}")
+if len(cnt) > 1:
+    import itertools
+    (ia, a), (ib, b) = list(outs.values())[:2]
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    per = d.reshape(d.shape[0], -1).max(axis=1)
+    print("  max |diff| per image:", np.round(per, 4).tolist(), "pixels differing:", int((d > 0).sum()), "of", d.size)

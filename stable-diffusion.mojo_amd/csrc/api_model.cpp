@@ -181,6 +181,7 @@ extern "C" int tsd_session_create(tsd_model* diffusion, tsd_model* decoder, int 
                o_img = carve(decoder ? (size_t)B * 3 * 64 * L * L * 4 : 0);
   hipError_t e = hipMalloc((void**)&s->state, off);
   if (e != hipSuccess) { delete s; TSD_FAIL(TSD_E_ALLOC, "session: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); }
+  if (ctx->opt.debug_poison >= 0 && (ctx->opt.debug_poison_what & 4)) hipMemsetAsync(s->state, ctx->opt.debug_poison & 255, off, ctx->stream);
   s->latents = (float*)(s->state + o_lat); s->lat2 = (float*)(s->state + o_lat2);
   s->ctx16 = (half_t*)(s->state + o_ctx); s->eps = (float*)(s->state + o_eps);
   s->tdev = (float*)(s->state + o_t); s->temb = (float*)(s->state + o_te);

@@ -74,6 +74,8 @@ struct TsdOptions {
   int gn_apply_mult = 2;   // TSD_GN_APPLY_MULT
   int gn_finalize_min = 2048;  // TSD_GN_FINALIZE_MIN: slab x group partial pairs per sample from which a separate k_gn_finalize launch finishes the statistics
   int debug_occ = 0;       // TSD_DEBUG_OCC
+  int debug_poison_what = 7;  // TSD_DEBUG_POISON_WHAT: 1 arena, 2 derived weights, 4 session state
+  int debug_poison = -1;   // TSD_DEBUG_POISON=<byte>: fresh device allocations (arena, session state, derived weights) are filled with it - a result that changes with the byte reads memory nobody wrote
   int bench_wrot = 1, bench_epi = 0, bench_altcfg = -1, gemm_ts = 0;  // microbenchmark only (tsd_debug_gemm_bench)
   unsigned gen = 0;        // bumped by every tsd_debug_set_* call on this context
 };

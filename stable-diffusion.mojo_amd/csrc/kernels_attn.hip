@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < ntiles; t++) {
+    tsd_jitter();
     f16v s[QB][2];
     if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
     {  // S^T - ref = K . Q^T + (-ref) of one 64-key tile: two 32-key blocks per query block, K fragments read once

@@ -100,8 +100,19 @@ __device__ __forceinline__ float gelu_tanh_c(float x) {  // helpers/utils.mojo:1
   const float t = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x2, k1, k0));
   return x * __builtin_amdgcn_rcpf(1.f + t);
 }
+// Counted waits and the callers' "EXTRA" loads (round 4, late - a real bug): a stage whose bias / residual loads are issued BEHIND the
+// first weight tiles used to add their number to the first four counted waits (vmcnt(15 + 25): "tile gt has landed, the three
+// younger tiles and my 25 loads may stay in flight").  The 25 was the SOURCE's count; hipcc merges the twenty 8-byte residual loads
+// pairwise where their addresses are adjacent and issues 17 instructions, so the wait let 8 OLDER instructions - tile gt's own
+// pieces - stay in flight too.  The tile had practically always landed anyway: 14 of 1500 fifty-step runs differed on one box, none
+// with the count removed (same speed: the younger tiles and loads have long been issued).  STRICT_WAIT = 1 (default): the counted
+// waits never include loads the compiler is free to merge, split or move - they are simply waited for as well.  0 = the old
+// counting (kept to reproduce the failure), 2 = every counted wait is vmcnt(0) (hazard hunting).
+#ifndef TSD_CHAIN_STRICT_WAIT
+#define TSD_CHAIN_STRICT_WAIT 1
+#endif
 template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TSD_CHAIN_STRICT_WAIT >= 2 ? 0 : N) : "memory"); }
 // An opaque use-and-redefine of a value: whatever computes it must be issued before this point and whatever consumes it after - it
 // ties side-effect-free arithmetic to its place between the MFMAs.  (A __device__ function so that the host pass never sees the "v"
 // constraint.)
@@ -128,6 +139,7 @@ __device__ __forceinline__ float rows_max(float v) {
   return fmaxf(a, b);
 }
 __device__ __forceinline__ void lds_barrier() {
+  tsd_jitter();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -297,16 +309,17 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       int off = 0, s4 = 0;
       const char *sA = smem, *sW = smem;
       if (have_next) {
+        tsd_jitter();
         // tile gt has landed: the three younger tiles (and the caller's EXTRA loads, which sit between tile gt+3 and tile
         // gt+4 of the stage's first tile in the queue) may stay in flight
         int younger = 0;
 #pragma unroll
         for (int d = 1; d <= 3; d++) { bool yg1, ylive; tile_off(SEG, gt + d, yg1, ylive); younger += yg1 ? 4 : 5; }
         switch (younger) {
-          case 12: if (EXTRA > 0 && kt < 4) wait_vm<12 + EXTRA>(); else wait_vm<12>(); break;
-          case 13: if (EXTRA > 0 && kt < 4) wait_vm<13 + EXTRA>(); else wait_vm<13>(); break;
-          case 14: if (EXTRA > 0 && kt < 4) wait_vm<14 + EXTRA>(); else wait_vm<14>(); break;
-          default: if (EXTRA > 0 && kt < 4) wait_vm<15 + EXTRA>(); else wait_vm<15>(); break;
+          case 12: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<12 + EXTRA>(); else wait_vm<12>(); break;
+          case 13: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<13 + EXTRA>(); else wait_vm<13>(); break;
+          case 14: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<14 + EXTRA>(); else wait_vm<14>(); break;
+          default: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<15 + EXTRA>(); else wait_vm<15>(); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile gt-1 are complete: its slot may be refilled
         if (TSD_CHAIN_TILE_BARRIER & 4) __builtin_amdgcn_s_sleep(1);
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   }
   load_cols(p.bco, bv);
   CTS(11);
-  wait_vm<5>();   // the context tiles have landed (the 5 bias loads are younger)
+  wait_vm<TSD_CHAIN_STRICT_WAIT ? 0 : 5>();   // the context tiles have landed (the 5 bias loads are younger)
   lds_barrier();  // q tile and context tiles visible
   CTS(12);
   // per wave: all 64 rows, heads 2*wn and 2*wn+1 (its own 80 columns of q: no other wave reads or writes them)
@@ -829,7 +842,8 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       int s4 = 0;
       const char *sA = smem, *sW = smem;
       if constexpr (CK != 0) {
-        constexpr int EX = (FLAGS & F_EXTRA) ? 4 : 0;
+        tsd_jitter();
+        constexpr int EX = ((FLAGS & F_EXTRA) && !TSD_CHAIN_STRICT_WAIT) ? 4 : 0;
         if constexpr (!(TSD_CHAIN_ABL & 32)) wait_vm<YG + EX>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile gt-1 (and any activation-tile writes) are complete
         // barriers only where the shared activation tile changes hands: before it is rewritten (F_WRITE steps: every wave has finished

@@ -15,3 +15,16 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int num_bytes = 0x
 __device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, unsigned soff, void* l) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
+
+// Hazard hunting (-DTSD_JITTER builds only, never shipped): a random wave-level delay at the points where waves meet or part.  A kernel
+// whose waves are correctly ordered gives the same bits whatever the delays; a hazard that a fixed schedule hides becomes a run-to-run
+// difference within a few launches (scripts/diag_race3.py counts distinct results).
+__device__ __forceinline__ void tsd_jitter() {
+#ifdef TSD_JITTER
+  const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+  if (((t >> 2) & 3) == 0) {
+    const int n = (int)((t >> 4) & 31);
+    for (int z = 0; z < n; z++) __builtin_amdgcn_s_sleep(4);
+  }
+#endif
+}

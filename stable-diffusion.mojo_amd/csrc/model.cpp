@@ -179,6 +179,7 @@ static int model_build_derived(tsd_model* m) {
       hipError_t e = hipMalloc((void**)&m->derived, need);
       if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "derived weights: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
       m->derived_bytes = need;
+      if (ctx->opt.debug_poison >= 0 && (ctx->opt.debug_poison_what & 2)) HIP_TRY(hipMemsetAsync(m->derived, ctx->opt.debug_poison & 255, need, ctx->stream));
     }
     const bool wp = ctx->arena.planning;
     ctx->arena.planning = false;
@@ -241,6 +242,7 @@ static int model_build_derived(tsd_model* m) {
     hipError_t e = hipMalloc((void**)&m->derived, need);
     if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "derived weights: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
     m->derived_bytes = need;
+    if (ctx->opt.debug_poison >= 0 && (ctx->opt.debug_poison_what & 2)) HIP_TRY(hipMemsetAsync(m->derived, ctx->opt.debug_poison & 255, need, ctx->stream));
   }
   const bool was_planning = ctx->arena.planning;
   ctx->arena.planning = false;

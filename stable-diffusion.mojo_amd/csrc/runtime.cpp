@@ -45,6 +45,8 @@ void options_from_env(TsdOptions& o) {
   o.gn_apply_mult = env_int("TSD_GN_APPLY_MULT", o.gn_apply_mult);
   o.gn_finalize_min = env_int("TSD_GN_FINALIZE_MIN", o.gn_finalize_min);
   o.debug_occ = getenv("TSD_DEBUG_OCC") ? 1 : 0;
+  o.debug_poison = env_int("TSD_DEBUG_POISON", o.debug_poison);
+  o.debug_poison_what = env_int("TSD_DEBUG_POISON_WHAT", o.debug_poison_what);
   o.bench_wrot = env_int("TSD_BENCH_WROT", o.bench_wrot); if (o.bench_wrot < 1) o.bench_wrot = 1;
   o.bench_epi = env_int("TSD_BENCH_EPI", o.bench_epi);
   o.bench_altcfg = env_int("TSD_BENCH_ALTCFG", o.bench_altcfg);
@@ -214,6 +216,7 @@ int ctx_reserve_arena(tsd_ctx* c, size_t bytes) {
   hipError_t e = hipMalloc((void**)&c->arena.base, want);
   if (e != hipSuccess) TSD_FAIL(TSD_E_ALLOC, "workspace arena: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
   c->arena.cap = want;
+  if (c->opt.debug_poison >= 0 && (c->opt.debug_poison_what & 1)) HIP_TRY(hipMemsetAsync(c->arena.base, c->opt.debug_poison & 255, want, c->stream));  // on the context's stream: ordered before everything that uses the arena
   return TSD_OK;
 }
 

@@ -558,6 +558,32 @@ def test_generate_is_bitwise_repeatable_under_stress(gpu_ctx, tsd_mod, diffusion
     assert len(hashes) == 1, f"{len(hashes)} distinct results from 10 identical generate() calls"
 
 
+def test_denoise_loop_is_bitwise_repeatable_200_runs(gpu_ctx, tsd_mod, diffusion):
+    """200 fifty-step denoise loops (8 latents, headline size) of ONE session on the same inputs give ONE result.  Round 4's second
+    hazard in the fused attention-block kernels changed about 1 run in 100 (a counted `s_waitcnt vmcnt` that included 25 bias / residual
+    loads of which the compiler issues 17: the first weight tile of a stage was not guaranteed to have landed) - ten generate() calls
+    above see that one time in ten; this sees it four times in five."""
+    import hashlib
+    from tsd.model import Session
+    B, L, T = 8, 64, 77
+    _, ctx = _inputs(B, L, tag=770)
+    nl = B * 4 * L * L
+    lat0 = rng.normal(37, 2, nl).reshape(B, 4, L, L)
+    sess = Session(diffusion.model, None, B, L, T, cfg=False)
+    sess.set_schedule(1000, 50, 0)
+    n = sess.num_steps
+    noise = rng.normal(37, 3, n * nl).reshape(n, B, 4, L, L)
+    hashes = {}
+    for r in range(200):
+        sess.upload(lat0, ctx, None, noise, 7.5)
+        for i in range(n):
+            sess.step(i)
+        hsh = hashlib.sha1(sess.latents().tobytes()).hexdigest()
+        hashes[hsh] = hashes.get(hsh, 0) + 1
+    sess.close()
+    assert len(hashes) == 1, f"{len(hashes)} distinct results from 200 identical denoise loops: {sorted(hashes.values())}"
+
+
 def test_img2img_matches_oracle_128px(gpu_ctx, tsd_mod, diffusion, decoder, unet_params, dec_params):
     """The img2img path against the oracle at a 16x16 latent (128 px): every level of the UNet has more than one tile
     row, the 64x64-level attention tail runs fused (S = 256 rows per sample)."""
