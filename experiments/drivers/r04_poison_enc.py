@@ -1,7 +1,7 @@
 """Which encoder call reads memory nobody wrote?  (TSD_DEBUG_POISON set by the caller.)"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "stable-diffusion.mojo_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import tsd
 from tsd import rng, checkpoint as ck
