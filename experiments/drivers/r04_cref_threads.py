@@ -1,6 +1,6 @@
 """One sample-step of the C restatement at several OpenMP team sizes on this host (which team size does the box allow?)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import cref, models, rng, spec
 print("affinity", len(os.sched_getaffinity(0)), "cpu_count", os.cpu_count(), "available", cref.threads_available())
