@@ -474,6 +474,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         constexpr int NP = A_PW + W_PW;
         static_assert(NW != 8 || LPS_HI == LPS_LO, "loader pieces must divide evenly");
         for (int kt = 0; kt < nk; kt++) {
+          tsd_jitter();
           const bool live = kt + 2 < nk;
           TileSrc t;
           if (live) t = tile_src(kt + 2, true);
@@ -495,6 +496,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         return;
       }
       for (int kt = 0; kt < nk; kt++) {
+        tsd_jitter();
         const int ahead = min(NS - 2, nk - 1 - kt);
         if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
         else if (NS >= 5 && ahead == 3) { if (lps_hi) wait_vmcnt<3 * LPS_HI>(); else wait_vmcnt<3 * LPS_LO>(); }
@@ -520,6 +522,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
     if (grp1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     int cur = 0;
     for (int kt = 0; kt < nk; kt++) {
+      tsd_jitter();
       const char* sA = smem + cur * TILE_BYTES;
       const char* sW = sA + BM * 128;
 #pragma unroll
@@ -573,6 +576,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         const char *sA = smem, *sW = smem;
         TileSrc t;
         if (have_next) {
+          tsd_jitter();
           if constexpr (LW == 0) {
           const int ahead = min(NS - 2, nk - 1 - kt);
           if (NS >= 6 && ahead >= 4) { if (lps_hi) wait_vmcnt<4 * LPS_HI>(); else wait_vmcnt<4 * LPS_LO>(); }
@@ -639,6 +643,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       }
     } else
     for (int kt = 0; kt < nk; kt++) {
+      tsd_jitter();
       // tiles issued beyond kt so far: min(NS-2, nk-1-kt); wait until tile kt has landed, keep the rest in flight
       if constexpr (LW == 0) {
       const int ahead = min(NS - 2, nk - 1 - kt);
@@ -748,6 +753,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       float* wsw = p.sk_ws + (((long long)(ks - 1) * ntile + tile) * NW + wave) * (FM * FN * 256);
       const rsrc_t rws = make_rsrc(wsw, FM * FN * 1024);
       wait_vmcnt<0>();  // dead tail DMA has landed before the wave may end
+      tsd_jitter();
 #pragma unroll
       for (int a = 0; a < FM; a++)
 #pragma unroll
@@ -781,6 +787,7 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
     }
   }
   // ---- epilogue ---------------------------------------------------------------------------
+  tsd_jitter();
   const int g = lane >> 4;
   // epilogue terms that only one kernel family uses are compiled out of the other (launch_gemm rejects the combinations):
   // GEGLU / per-row bias exist for dense GEMMs only, the time-embedding row vector / upsampled residual for conv3x3 only
