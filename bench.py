@@ -12,6 +12,12 @@ synthetic latents/context (there is no network for checkpoints or datasets).
 N > 1: one process per GPU; the batch of independent prompts is sharded (8 per rank, weak scaling), the
 only collective is the one-time RCCL broadcast of the packed weights from rank 0 (outside the timed
 region).  Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` started PLAINLY (no WORLD_SIZE in the environment) launches its own N ranks: it re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per visible
+device.  The line never lies about N: fewer than N visible devices, or a WORLD_SIZE that differs from --gpus, is an error
+(exit status 2), and `n_gpus` is asserted equal to --gpus before anything is printed; `rccl_ranks` reports the size of the
+communicator that actually ran (torch.distributed's world size, and ncclCommCount on the library's own RCCL path).
 """
 import argparse
 import ctypes
@@ -110,6 +116,9 @@ def broadcast_weights_native(models, ctx, rank, world):
             m.mark_loaded()
         nbytes += m.packed_blob()[1]
     ctx.synchronize()
+    cnt = ctypes.c_int(0)
+    check(lib().tsd_dist_comm_count(ctx.h, ctypes.byref(cnt)))
+    assert cnt.value == world, f"ncclCommCount says {cnt.value} ranks, the launcher {world}"
     check(lib().tsd_dist_finalize(ctx.h))
     return time.time() - t0, nbytes
 
@@ -207,6 +216,52 @@ def cpu_baseline(L, T):
     return t_c, n_thr, t_np, reps
 
 
+def visible_devices():
+    """HIP devices this process can see (through libtsd: the product's own view, HIP_VISIBLE_DEVICES applied)."""
+    from tsd._lib import lib
+    return int(lib().tsd_device_count())
+
+
+def self_launch(n):
+    """`bench.py --gpus N` without a launcher: start N ranks of this same command line under torch.distributed.run, one per visible
+    device (TSD_BENCH_DEVICE / TSD_BENCH_BACKEND=gloo - the one-GPU exercise of the N > 1 path - lift the device-count check).
+    Returns the exit status to leave with."""
+    import socket
+    import subprocess
+    one_device = "TSD_BENCH_DEVICE" in os.environ or os.environ.get("TSD_BENCH_LAUNCH_ONLY") == "1"
+    if not one_device:
+        have = visible_devices()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible: refusing to run", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    print(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:7])} ...", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_only(rank, world, args):
+    """TSD_BENCH_LAUNCH_ONLY=1: rendezvous, count the ranks, print the launcher's half of the line - no GPU touched.  How the CPU
+    test-suite checks that `bench.py --gpus 2`, started plainly, really is two ranks."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("TSD_BENCH_BACKEND", "gloo"))
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    ranks = int(t.item())
+    ok = ranks == world == args.gpus == dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "rccl_ranks": {"torch_distributed": dist.get_world_size(), "counted": ranks},
+                          "shards": [list(shard_range(world * args.batch, r, world)) for r in range(world)]}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,12 +286,21 @@ def main():
     args.img2img = not (args.no_img2img or args.no_extras or args.no_decode)
     args.sd15 = not (args.no_sd15 or args.no_extras)
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != args.gpus:
+        # a line that says n_gpus = 1 for a run asked to measure 8 (or the reverse) is worse than no line
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run (launch with --nproc-per-node {args.gpus}, "
+              "or plainly and let bench.py start its own ranks)", file=sys.stderr)
+        sys.exit(2)
     B, L, T = args.batch, args.latent, args.tokens
+    if os.environ.get("TSD_BENCH_LAUNCH_ONLY") == "1":
+        sys.exit(launch_only(rank, world, args))
 
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before anything initialises HIP (see tsd/_lib.py)
     if world > 1 or os.environ.get("TSD_BENCH_FORCE_DIST") == "1":
@@ -266,12 +330,15 @@ def main():
     unet = tsd.Diffusion(seed=SEED if rank == 0 else None, ctx=ctx)
     dec = None if args.no_decode else tsd.Decoder(seed=SEED if rank == 0 else None, ctx=ctx)
     bcast_s, bcast_bytes, bcast_how = 0.0, 0, "none (single GPU)"
+    rccl_ranks = {"torch_distributed": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
+                  "ncclCommCount_native": None}
     if use_dist:
         models = [unet.model] + ([dec.model] if dec is not None else [])
         # a failed broadcast is FATAL: a multi-GPU run that silently re-initialised every rank from the seed would hide
         # exactly the failure the run exists to detect
         if os.environ.get("TSD_BENCH_NATIVE_DIST") == "1":
             bcast_s, bcast_bytes = broadcast_weights_native(models, ctx, rank, world)
+            rccl_ranks["ncclCommCount_native"] = world  # asserted inside
             bcast_how = "rccl broadcast of the packed blobs from rank 0 by libtsd itself (tsd_dist_*; unique id over torch.distributed)"
         else:
             bcast_s, bcast_bytes = broadcast_weights(models, rank, world, f"cuda:{dev_index}", backend)
@@ -510,9 +577,10 @@ def main():
                    "numpy_oracle": {"value": round(1.0 / (B * t_numpy), 6), "cores": c_threads,
                                     "sample": f"the same sample-step on the numpy oracle (im2col + BLAS) took {t_numpy:.1f} s"}}
         whole_frac = steps_per_s / world * B * total_gf / 1e3 / PEAK_FP16_TFLOPS
+        assert world == args.gpus and rccl_ranks["torch_distributed"] == world, (world, args.gpus, rccl_ranks)
         line = {
             "metric": "UNet denoising steps/sec @ 512x512 latent, batch=8", "value": round(steps_per_s, 3),
-            "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4),
+            "unit": "steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"Tiny-SD UNet 512x512 (latent 4x{L}x{L}), batch {B}/GPU, {n_sched}-step DDPM schedule, "
                                    f"{T}-token context, no CFG, random-init weights (BASELINE configs[1])",

@@ -275,6 +275,8 @@ int tsd_session_download_images(tsd_session* s, int rescale_0_255, float* images
 int tsd_dist_unique_id(void* id128);
 int tsd_dist_init(tsd_ctx* ctx, int rank, int nranks, const void* id128);
 int tsd_dist_broadcast_weights(tsd_model* m, int root); /* ncclBroadcast of the packed blob */
+/* ranks of the communicator tsd_dist_init created (ncclCommCount): what RCCL itself holds, not what the caller passed in */
+int tsd_dist_comm_count(tsd_ctx* ctx, int* nranks);
 int tsd_dist_finalize(tsd_ctx* ctx);
 
 /* ---- debug / tuning -------------------------------------------------------------------- */

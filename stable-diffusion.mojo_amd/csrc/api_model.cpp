@@ -375,10 +375,12 @@ typedef int (*fn_init_rank)(void**, int, nccl_uid, int);
 typedef int (*fn_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(void*, int*);
 struct Rccl {
   void* lib = nullptr;
   fn_get_uid get_uid = nullptr; fn_init_rank init_rank = nullptr; fn_bcast bcast = nullptr; fn_destroy destroy = nullptr;
   fn_errstr errstr = nullptr;
+  fn_count count = nullptr;
 };
 Rccl g_rccl;
 int rccl_load() {
@@ -403,6 +405,7 @@ int rccl_load() {
   g_rccl.bcast = (fn_bcast)dlsym(g_rccl.lib, "ncclBroadcast");
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.lib, "ncclCommDestroy");
   g_rccl.errstr = (fn_errstr)dlsym(g_rccl.lib, "ncclGetErrorString");
+  g_rccl.count = (fn_count)dlsym(g_rccl.lib, "ncclCommCount");
   if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.bcast || !g_rccl.destroy)
     TSD_FAIL(TSD_E_RCCL, "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclBroadcast");
   return TSD_OK;
@@ -445,6 +448,14 @@ extern "C" int tsd_dist_broadcast_weights(tsd_model* m, int root) {
   RCCL_TRY(g_rccl.bcast(m->blob, m->blob, m->blob_bytes, 0 /*ncclInt8*/, root, ctx->rccl_comm, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return tsd_model_mark_loaded(m);
+}
+
+extern "C" int tsd_dist_comm_count(tsd_ctx* ctx, int* nranks) {
+  NOTNULL(ctx); NOTNULL(nranks);
+  if (!ctx->rccl_comm) TSD_FAIL(TSD_E_STATE, "dist: tsd_dist_init was not called on this context");
+  if (!g_rccl.count) TSD_FAIL(TSD_E_RCCL, "librccl has no ncclCommCount");
+  RCCL_TRY(g_rccl.count(ctx->rccl_comm, nranks));
+  return TSD_OK;
 }
 
 extern "C" int tsd_dist_finalize(tsd_ctx* ctx) {

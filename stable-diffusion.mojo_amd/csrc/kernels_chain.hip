@@ -111,8 +111,12 @@ __device__ __forceinline__ float gelu_tanh_c(float x) {  // helpers/utils.mojo:1
 #ifndef TSD_CHAIN_STRICT_WAIT
 #define TSD_CHAIN_STRICT_WAIT 1
 #endif
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TSD_CHAIN_STRICT_WAIT >= 2 ? 0 : N) : "memory"); }
+// DMA pieces of younger tiles (4 per GEMM-1 quarter tile, 5 per full one) + OTHER plain loads may stay in flight; the accounting
+// travels into the assembly and tools/isa_lint.py checks it against what hipcc emitted (lds_dma.h)
+template <int DMA, int OTHER = 0>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (TSD_CHAIN_STRICT_WAIT >= 2) wait_vm_counted<0>(); else wait_vm_counted<DMA, OTHER, 5, 4>();
+}
 // An opaque use-and-redefine of a value: whatever computes it must be issued before this point and whatever consumes it after - it
 // ties side-effect-free arithmetic to its place between the MFMAs.  (A __device__ function so that the host pass never sees the "v"
 // constraint.)
@@ -315,12 +319,14 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
         int younger = 0;
 #pragma unroll
         for (int d = 1; d <= 3; d++) { bool yg1, ylive; tile_off(SEG, gt + d, yg1, ylive); younger += yg1 ? 4 : 5; }
+        wait_alt_begin();  // exactly one of the four runs
         switch (younger) {
-          case 12: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<12 + EXTRA>(); else wait_vm<12>(); break;
-          case 13: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<13 + EXTRA>(); else wait_vm<13>(); break;
-          case 14: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<14 + EXTRA>(); else wait_vm<14>(); break;
-          default: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<15 + EXTRA>(); else wait_vm<15>(); break;
+          case 12: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<12, EXTRA>(); else wait_vm<12>(); break;
+          case 13: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<13, EXTRA>(); else wait_vm<13>(); break;
+          case 14: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<14, EXTRA>(); else wait_vm<14>(); break;
+          default: if (EXTRA > 0 && kt < 4 && !TSD_CHAIN_STRICT_WAIT) wait_vm<15, EXTRA>(); else wait_vm<15>(); break;
         }
+        wait_alt_end();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile gt-1 are complete: its slot may be refilled
         if (TSD_CHAIN_TILE_BARRIER & 4) __builtin_amdgcn_s_sleep(1);
         if (!have_prev || (TSD_CHAIN_TILE_BARRIER & 1)) __builtin_amdgcn_s_barrier();  // stage start: the A operand every wave wrote a part of is complete
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
   }
   load_cols(p.bco, bv);
   CTS(11);
-  wait_vm<TSD_CHAIN_STRICT_WAIT ? 0 : 5>();   // the context tiles have landed (the 5 bias loads are younger)
+  wait_vm<0, TSD_CHAIN_STRICT_WAIT ? 0 : 5>();   // the context tiles have landed (the 5 bias loads are younger)
   lds_barrier();  // q tile and context tiles visible
   CTS(12);
   // per wave: all 64 rows, heads 2*wn and 2*wn+1 (its own 80 columns of q: no other wave reads or writes them)
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(256, 1) void attn_chain_kernel(const TailK p) {
       if constexpr (CK != 0) {
         tsd_jitter();
         constexpr int EX = ((FLAGS & F_EXTRA) && !TSD_CHAIN_STRICT_WAIT) ? 4 : 0;
-        if constexpr (!(TSD_CHAIN_ABL & 32)) wait_vm<YG + EX>();
+        if constexpr (!(TSD_CHAIN_ABL & 32)) wait_vm<YG, EX>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of tile gt-1 (and any activation-tile writes) are complete
         // barriers only where the shared activation tile changes hands: before it is rewritten (F_WRITE steps: every wave has finished
         // the previous chunk's GEMM-2 reads) and before its first GEMM-2 read (F_SYNC: every wave's part is written)

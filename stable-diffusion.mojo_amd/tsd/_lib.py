@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtsd.so")
+# TSD_LIB names another build of the same library (the -DTSD_JITTER hazard-hunting build of `make jitter`); never a different backend
+LIB_PATH = os.environ.get("TSD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libtsd.so")
 
 TSD_OK, TSD_E_ARG, TSD_E_SHAPE, TSD_E_ALLOC, TSD_E_HIP, TSD_E_RCCL, TSD_E_STATE, TSD_E_NONFINITE = 0, -1, -2, -3, -4, -5, -6, -7
 # Kernel arguments in device memory instead of host-coherent memory: every kernel starts by reading its ~200 B argument
@@ -104,6 +105,7 @@ def _declare(l):
         "tsd_session_download_latents": ([vp, fp], i), "tsd_session_download_images": ([vp, i, fp], i),
         "tsd_dist_unique_id": ([vp], i), "tsd_dist_init": ([vp, i, i, vp], i),
         "tsd_dist_broadcast_weights": ([vp, i], i), "tsd_dist_finalize": ([vp], i),
+        "tsd_dist_comm_count": ([vp, C.POINTER(i)], i),
         "tsd_flop_count": ([i, i, i], C.c_double),
         "tsd_debug_splitk_errors": ([vp], i),
         "tsd_debug_xcd_round_robin": ([], i),

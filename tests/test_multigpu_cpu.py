@@ -93,3 +93,46 @@ def test_shard_range_partitions(total, world):
         lo, hi = bench.shard_range(total, r, world)
         seen += list(range(lo, hi))
     assert seen == list(range(total))
+
+
+# ---- bench.py --gpus N started plainly: it launches its own N ranks and refuses to print a line about another N --------------------
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=timeout)
+
+
+def test_bench_gpus_2_started_plainly_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: two ranks rendezvous over gloo on 127.0.0.1 and rank 0 reports
+    n_gpus = 2 (TSD_BENCH_LAUNCH_ONLY=1 stops before the first GPU call - there is no GPU here)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"TSD_BENCH_LAUNCH_ONLY": "1", "TSD_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == {"torch_distributed": 2, "counted": 2}
+    assert line["shards"] == [[0, 8], [8, 16]]
+    assert "starting 2 ranks" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    r = _run_bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "TSD_BENCH_LAUNCH_ONLY": "1"}, timeout=60)
+    assert r.returncode == 2 and "refusing to run" in r.stderr, (r.returncode, r.stderr[-500:])
+    r = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "1", "RANK": "0", "TSD_BENCH_LAUNCH_ONLY": "1"}, timeout=60)
+    assert r.returncode == 2 and "refusing to run" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """No HIP device in this container: `--gpus 2` started plainly must exit non-zero before it launches anything."""
+    sys.path.insert(0, os.path.join(ROOT, "stable-diffusion.mojo_amd"))
+    from tsd._lib import lib
+    if lib().tsd_device_count() >= 2:
+        pytest.skip("two devices visible")
+    r = _run_bench(["--gpus", "2"], {}, timeout=120)
+    assert r.returncode == 2 and "HIP device(s) visible: refusing to run" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
