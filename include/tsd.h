@@ -283,8 +283,12 @@ int tsd_dist_finalize(tsd_ctx* ctx);
 /* Every switch below belongs to ONE context: the library keeps no process-global mutable state besides the thread-local error
  * string, so two contexts (one per GPU, each driven by its own host thread) may run different settings side by side.  The
  * TSD_* environment variables named here are read once, by tsd_ctx_create, into that context.  A denoise session sizes its
- * workspace for the settings active at upload(): after a tsd_debug_set_* call on its context, step() / decode() fail with
- * TSD_E_STATE until upload() is called again. */
+ * workspace for the settings active at upload(): after a tsd_debug_set_* call that CHANGES a setting of its context, step() /
+ * decode() fail with TSD_E_STATE until upload() is called again (setting the value that is already there changes nothing).
+ * Every tsd_debug_set_* returns the previous setting, always >= 0; an out-of-range value is ignored; the only negative
+ * return is TSD_E_ARG (-1) for a NULL context.
+ * Non-finite results are sticky per SESSION: once a session download has returned TSD_E_NONFINITE, every later step(), decode()
+ * and download of that session returns it again until upload() replaces the session's state. */
 /* split-K hand-offs that timed out or paired blocks on different XCDs since the context was created (must be 0);
  * 1 when workgroups map to XCDs round-robin (the precondition of the L2-local split-K hand-off). */
 int tsd_debug_splitk_errors(tsd_ctx* ctx);

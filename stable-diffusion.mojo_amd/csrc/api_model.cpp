@@ -138,7 +138,28 @@ struct tsd_session {
   bool uploaded = false, has_noise = false;
   size_t plan_unet = 0, plan_dec = 0;
   unsigned opt_gen = 0;  // generation of the context's options the workspace was sized for (upload)
+  // Latched when a download found inf / NaN in this session's state (or the context reported TSD_E_NONFINITE at one of this session's
+  // synchronisation points): the context's counter is cleared once reported, the latents stay what they are - every later step,
+  // decode and download of THIS session fails with TSD_E_NONFINITE until upload() replaces the state.
+  bool poisoned = false;
 };
+
+// inf / NaN scan of a downloaded tensor (exponent bits all ones); the buffers at this boundary are 0.5 - 25 MB
+static bool host_all_finite(const float* p, size_t n) {
+  unsigned bad = 0;
+  for (size_t i = 0; i < n; i++) {
+    unsigned u;
+    memcpy(&u, p + i, 4);
+    bad |= ((u & 0x7f800000u) == 0x7f800000u);
+  }
+  return bad == 0;
+}
+#define SESSION_NOT_POISONED(s)                                                                                              \
+  do {                                                                                                                       \
+    if ((s)->poisoned)                                                                                                       \
+      TSD_FAIL(TSD_E_NONFINITE, "session: inf / NaN was found in this session's latents or images (reported at an earlier " \
+               "download); its state is unusable until upload() replaces it");                                              \
+  } while (0)
 
 static void build_schedule(tsd_session* s) {
   // betas = linspace(sqrt(b0), sqrt(b1), N)^2 ; alphas_cumprod = cumprod(1 - betas)   (sampler.mojo:28-32), fp32
@@ -270,6 +291,7 @@ extern "C" int tsd_session_upload(tsd_session* s, const float* latents, const fl
   TSD_TRY(ctx_reserve_arena(ctx, need));
   s->opt_gen = ctx->opt.gen;
   s->uploaded = true;
+  s->poisoned = false;
   return TSD_OK;
 }
 
@@ -291,6 +313,7 @@ static void ddpm_coeffs(const tsd_session* s, int t, float* sa, float* sb, float
 extern "C" int tsd_session_step(tsd_session* s, int i) {
   NOTNULL(s);
   if (!s->uploaded) TSD_FAIL(TSD_E_STATE, "session: upload() before step()");
+  SESSION_NOT_POISONED(s);
   if (s->opt_gen != s->ctx->opt.gen) TSD_FAIL(TSD_E_STATE, "session: a tsd_debug_set_* call changed this context's options after upload() sized the workspace; upload() again");
   if (i < 0 || i >= (int)s->timesteps.size()) TSD_FAIL(TSD_E_ARG, "session: step %d out of range", i);
   tsd_ctx* ctx = s->ctx;
@@ -334,6 +357,7 @@ extern "C" int tsd_session_decode(tsd_session* s) {
   NOTNULL(s);
   if (!s->dec) TSD_FAIL(TSD_E_STATE, "session: created without a decoder");
   if (!s->uploaded) TSD_FAIL(TSD_E_STATE, "session: upload() before decode()");
+  SESSION_NOT_POISONED(s);
   if (s->opt_gen != s->ctx->opt.gen) TSD_FAIL(TSD_E_STATE, "session: a tsd_debug_set_* call changed this context's options after upload() sized the workspace; upload() again");
   s->ctx->arena.top = 0;
   int r = g_decoder_forward(s->dec, s->latents, s->B, s->L, s->images);
@@ -343,9 +367,18 @@ extern "C" int tsd_session_decode(tsd_session* s) {
 
 extern "C" int tsd_session_download_latents(tsd_session* s, float* latents) {
   NOTNULL(s); NOTNULL(latents);
-  HIP_TRY(hipMemcpyAsync(latents, s->latents, (size_t)s->B * 4 * s->L * s->L * 4, hipMemcpyDeviceToHost, s->ctx->stream));
+  const size_t n = (size_t)s->B * 4 * s->L * s->L;
+  HIP_TRY(hipMemcpyAsync(latents, s->latents, n * 4, hipMemcpyDeviceToHost, s->ctx->stream));
   HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-  TSD_TRY(ctx_check_status(s->ctx));
+  const int r = ctx_check_status(s->ctx);
+  if (r == TSD_E_NONFINITE) s->poisoned = true;
+  if (r != TSD_OK) return r;
+  // the context's count may have been reported (and cleared) at another model's synchronisation point, or by an earlier call: what
+  // leaves the device HERE is checked itself
+  if (s->poisoned || !host_all_finite(latents, n)) {
+    s->poisoned = true;
+    SESSION_NOT_POISONED(s);
+  }
   return TSD_OK;
 }
 
@@ -362,7 +395,14 @@ extern "C" int tsd_session_download_images(tsd_session* s, int rescale_0_255, fl
   }
   HIP_TRY(hipMemcpyAsync(images, src, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return ctx_check_status(ctx);
+  const int r = ctx_check_status(ctx);
+  if (r == TSD_E_NONFINITE) s->poisoned = true;
+  if (r != TSD_OK) return r;
+  if (s->poisoned || !host_all_finite(images, (size_t)n)) {
+    s->poisoned = true;
+    SESSION_NOT_POISONED(s);
+  }
+  return TSD_OK;
 }
 
 // ---- RCCL weight broadcast over xGMI ---------------------------------------

@@ -145,6 +145,17 @@ int ctx_check_splitk(tsd_ctx* ctx);
 // ... and TSD_E_NONFINITE if inf / NaN reached a caller-visible tensor since the last report (count cleared once reported).  Every
 // synchronisation point of the ABI calls this one; it includes ctx_check_splitk.
 int ctx_check_status(tsd_ctx* ctx);
+// Body of the tsd_debug_set_* switches: the option takes `v` if lo <= v <= hi; the option generation (which invalidates the workspace
+// plan of uploaded sessions) moves only when the stored value really CHANGES - restoring the value that is already there in a
+// try / finally does not cost every session of the context an upload().  Returns the previous value (>= 0); TSD_E_ARG (< 0) for a
+// NULL context is the only negative return.
+inline int ctx_set_option(tsd_ctx* ctx, int TsdOptions::*field, int v, int lo, int hi) {
+  if (!ctx) return TSD_E_ARG;
+  const int prev = ctx->opt.*field;
+  if (v >= lo && v <= hi && v != prev) { ctx->opt.*field = v; ctx->opt.gen++; }
+  return prev;
+}
+
 int ctx_reserve_staging(tsd_ctx* ctx, size_t bytes);
 
 // ---- device tensor views (NHWC fp16 activations) ---------------------------------------

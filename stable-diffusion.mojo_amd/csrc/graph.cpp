@@ -91,10 +91,7 @@ int g_linear(tsd_ctx* ctx, const CatSrc& a, int64_t M, const half_t* w, int ldw,
 // q/k/v projection as one GEMM with a transposed tail (GemmArgs::Vt): whole 32-token passes per sample, V columns on a tile boundary
 // The graph-shape switches live in the context (TsdOptions); a setter changes THAT context only and returns the old value.
 extern "C" int tsd_debug_set_qkv_fuse(tsd_ctx* ctx, int on) {
-  if (!ctx) return TSD_E_ARG;
-  const int prev = ctx->opt.qkv_fuse;
-  if (on == 0 || on == 1) { ctx->opt.qkv_fuse = on; ctx->opt.gen++; }
-  return prev;
+  return ctx_set_option(ctx, &TsdOptions::qkv_fuse, on, 0, 1);
 }
 static bool qkv_fused_ok(const tsd_ctx* ctx, int S, int Sp, int C) {
   const int BN = ((3 * C) % 160 == 0) ? 160 : 128;
@@ -116,10 +113,7 @@ static NormSrc norm_src(const CatSrc& x, int C) {
 }
 
 extern "C" int tsd_debug_set_res_fuse_skip(tsd_ctx* ctx, int on) {
-  if (!ctx) return TSD_E_ARG;
-  const int prev = ctx->opt.res_fuse_skip;
-  if (on == 0 || on == 1) { ctx->opt.res_fuse_skip = on; ctx->opt.gen++; }
-  return prev;
+  return ctx_set_option(ctx, &TsdOptions::res_fuse_skip, on, 0, 1);
 }
 
 // `Unet_Residual_Block.forward` diffusion.mojo:54-72 / VAE `Res_Block.forward` vae.mojo:57-67

@@ -505,16 +505,10 @@ bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
 // per-context switches (TsdOptions): attn_diag 0 = optimistic reference from key tile 0 only (the round-2 behaviour);
 // attn_qb_force 0 = 32- / 64-query waves chosen by the layer shape, 1 / 2 = that many query blocks per wave whenever d = 40
 extern "C" int tsd_debug_set_attn_diag(tsd_ctx* ctx, int on) {
-  if (!ctx) return TSD_E_ARG;
-  const int prev = ctx->opt.attn_diag;
-  if (on == 0 || on == 1) { ctx->opt.attn_diag = on; ctx->opt.gen++; }
-  return prev;
+  return ctx_set_option(ctx, &TsdOptions::attn_diag, on, 0, 1);
 }
 extern "C" int tsd_debug_set_attn_qb(tsd_ctx* ctx, int mode) {
-  if (!ctx) return TSD_E_ARG;
-  const int prev = ctx->opt.attn_qb_force;
-  if (mode >= 0 && mode <= 2) { ctx->opt.attn_qb_force = mode; ctx->opt.gen++; }
-  return prev;
+  return ctx_set_option(ctx, &TsdOptions::attn_qb_force, mode, 0, 2);
 }
 template <int D, int QB>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {

@@ -1076,11 +1076,7 @@ size_t attn_tail_stream_bytes() { return (size_t)STREAM_BYTES; }
 
 // debug / A-B switch of ONE context: 1 = fused head / tail kernels at the 64x64 level (default), 0 = the op-by-op graph; returns the old value
 extern "C" int tsd_debug_set_fused_attention(tsd_ctx* ctx, int on) {
-  if (!ctx) return TSD_E_ARG;
-  const int old = ctx->opt.chain;
-  ctx->opt.chain = on ? 1 : 0;
-  ctx->opt.gen++;
-  return old;
+  return ctx_set_option(ctx, &TsdOptions::chain, on ? 1 : 0, 0, 1);
 }
 bool attn_tail_supported(const tsd_ctx* ctx, int C_, int d, int heads, int T, int64_t M, int S) {
   return ctx->opt.chain && C_ == 320 && d == 40 && heads == 8 && T >= 1 && T <= 80 && S % 64 == 0 && M % 64 == 0 && M < (1 << 24);

@@ -1386,6 +1386,17 @@ static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
   return launch_by_id<CONV>(ctx, k, batch, id);
 }
 
+// The bench / check entries below pin the tile configuration through the context; the guard puts "dispatcher's choice" back on EVERY
+// way out (a HIP_TRY / TSD_TRY early return used to leave later launches of the context pinned: ADVICE r04)
+namespace {
+struct ForceCfgGuard {
+  tsd_ctx* ctx;
+  ForceCfgGuard(tsd_ctx* c, int cfg) : ctx(c) { ctx->opt.force_cfg = cfg; }
+  ~ForceCfgGuard() { ctx->opt.force_cfg = -1; }
+  void set(int cfg) { ctx->opt.force_cfg = cfg; }
+};
+}  // namespace
+
 // Debug/bench entry: time `iters` launches of one GEMM / conv3x3 problem on synthetic device data with a forced
 // tile configuration (cfg < 0: the dispatcher's choice).  conv: M = B*Ho*Wo from (B,H,W,stride,ups), K = 9*Cin.
 extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W, int Cin, int N, int stride, int ups,
@@ -1426,7 +1437,7 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
     if (epi_mode == 1) { HIP_TRY(hipMemsetAsync(R, 0, (size_t)nc * 2, ctx->stream)); g.R = R; g.ldr = N; g.epi |= EPI_RESIDUAL; }
     else { g.epi |= EPI_GEGLU; g.ldc = N / 2; }
   }
-  ctx->opt.force_cfg = cfg;
+  ForceCfgGuard forced(ctx, cfg);
   int r = launch_gemm(ctx, g);
   if (r == TSD_OK) r = launch_gemm(ctx, g);
 #ifdef TSD_GEMM_TS
@@ -1461,15 +1472,14 @@ extern "C" int tsd_debug_gemm_bench(tsd_ctx* ctx, int conv, int B, int H, int W,
     }
   }
 #endif
-  if (r != TSD_OK) { ctx->opt.force_cfg = -1; return r; }
+  if (r != TSD_OK) return r;
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
   const int alt = ctx->opt.bench_altcfg;  // alternate two kernels (cold I-cache probe)
   for (int i = 0; i < iters && r == TSD_OK; i++) {
-    if (alt >= 0) ctx->opt.force_cfg = (i & 1) ? alt : cfg;
+    if (alt >= 0) forced.set((i & 1) ? alt : cfg);
     g.Wt = Wt + (int64_t)(i % wrot) * nw1;
     r = launch_gemm(ctx, g);
   }
-  ctx->opt.force_cfg = -1;
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));
   float t = 0.f;
@@ -1505,11 +1515,14 @@ extern "C" int tsd_debug_gemm_check(tsd_ctx* ctx, int conv, int B, int H, int W,
   GemmArgs g;
   g.A0 = A; g.lda0 = Cin; g.Wt = Wt; g.ldw = (int)K; g.M = (int)M; g.N = N; g.K = (int)K; g.ldc = N;
   if (conv) { g.conv = 1; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo; g.Cin = Cin; g.stride = stride; g.pad = 1; g.ups = ups; }
-  g.C = C0; ctx->opt.force_cfg = ref_cfg;
-  int r = launch_gemm(ctx, g);
-  g.C = C1; ctx->opt.force_cfg = cfg;
-  if (r == TSD_OK) r = launch_gemm(ctx, g);
-  ctx->opt.force_cfg = -1;
+  int r;
+  {
+    ForceCfgGuard forced(ctx, ref_cfg);
+    g.C = C0;
+    r = launch_gemm(ctx, g);
+    g.C = C1; forced.set(cfg);
+    if (r == TSD_OK) r = launch_gemm(ctx, g);
+  }
   if (r != TSD_OK) return r;
   std::vector<half_t> h0(nc), h1(nc);
   HIP_TRY(hipMemcpyAsync(h0.data(), C0, nc * 2, hipMemcpyDeviceToHost, ctx->stream));

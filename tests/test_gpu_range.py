@@ -223,6 +223,16 @@ def test_module_forward_overflow_is_reported(gpu_ctx, tsd_mod, diffusion):
     with pytest.raises(tsd_mod.TsdError) as e2:
         sess.latents()
     assert e2.value.code == TSD_E_NONFINITE
+    # the report is STICKY for the session (the context's counter was cleared by the first report; the NaN latents are still there):
+    # a retry of the download, the next step and a decode all fail until upload() replaces the state
+    assert lib().tsd_debug_nonfinite_count(gpu_ctx.h, 0) == 0
+    for again in (sess.latents, lambda: sess.step(1)):
+        with pytest.raises(tsd_mod.TsdError) as e3:
+            again()
+        assert e3.value.code == TSD_E_NONFINITE
+    sess.upload(lat[0:1] / np.float32(1e6), ctx, None, None)
+    sess.step(0)
+    assert np.isfinite(sess.latents()).all()
     sess.close()
     assert lib().tsd_debug_nonfinite_count(gpu_ctx.h, 1) >= 0
 
