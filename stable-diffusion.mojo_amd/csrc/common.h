@@ -67,7 +67,7 @@ struct TsdOptions {
   int attn_xcd = 0;        // TSD_ATTN_XCD: XCD-aware (head, query tile) map
   // GEMM / conv dispatch (kernels_gemm.hip)
   int xcdn = 0, conv_halo = 0, splitk = 1, splitk_mink = 4096, splitk_tiles = 256, splitk_small = 8, splitk_wide = 1, splitk_ring4 = 0,
-      splitk_big = 0, sk_cfg = 5, thin_cfg = 0, tune = 15, sk256 = 0;  // sk256: TSD_GEMM_SK256 (256-row tiles for split-K launches)
+      splitk_big = 0, sk_cfg = 5, thin_cfg = 0, tune = 15, sk256 = 0, skip128 = 1;  // sk256: TSD_GEMM_SK256 (256-row tiles for split-K launches)
   int force_cfg = -1;      // tsd_debug_gemm_bench / _check: tile configuration forced for the launches of this context
   int sk_big_graph = 0;    // slices of the long-K split launches asked for by the graph being enqueued (gemm_set_splitk_big)
   char cfg_override[512] = "";  // TSD_GEMM_CFG_OVERRIDE

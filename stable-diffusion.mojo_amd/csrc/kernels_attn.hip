@@ -43,6 +43,9 @@
 #ifndef TSD_ATTN_ABL
 #define TSD_ATTN_ABL 0
 #endif
+#ifndef TSD_ATTN_CHECK_EVERY
+#define TSD_ATTN_CHECK_EVERY 8  // key tiles between two looks at the row sums in the optimistic softmax pass (early abort, below)
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
   constexpr int K_INSTR = KPITCH, V_INSTR = D / 8;
   constexpr int K_PW = (K_INSTR + 3) / 4, V_PW = (V_INSTR + 3) / 4;
   constexpr int BUF_BYTES = K_BYTES + V_BYTES;
+  constexpr int FLAG_OFF = NST * BUF_BYTES;  // one word behind the tile buffers: "some row of this workgroup overflowed" (early abort, below)
   // Row sums for free: when the 32-row d blocks have a spare row (d = 40, 80) V^T row D is all ones, so the P.V MFMA
   // also accumulates l = sum_k P[q][k] in O^T row D - rescaled with O, and summed over the SAME fp16-rounded P.
   constexpr bool ONES_ROW = VROWS > D;
@@ -261,6 +265,14 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
   f16v nm[QB];
   const int vkey = (lane >> 1) & 7;  // swizzle key of V^T row (db*32 + l31)
 
+  // Early abort of the optimistic pass (round 5).  An overflow used to be noticed after the LAST tile only, so a workgroup that had to
+  // repeat paid a whole optimistic pass first: with peaked logits (every workgroup repeating) the kernel took 2x.  The row sum (row D of
+  // O^T, fed by the ones row of V^T) is infinite from the overflowing tile on; every eighth tile each wave looks at it - one compare per
+  // query block - raises a flag in LDS in front of the tile's barrier, and all waves leave together behind it.  Same decision as
+  // the final check (an inf never leaves the sum), so the results are the ones of the unabridged pass; d = 160 (no ones row, at most
+  // 4 tiles at the 16x16 level) keeps the final check only.
+  constexpr int CHECK_EVERY = TSD_ATTN_CHECK_EVERY;  // (a huge value = the round-4 behaviour: final check only; for same-box A/B builds)
+  if (tid == 0) *(volatile int*)(smem + FLAG_OFF) = 0;  // published by run()'s first barrier
   auto run = [&](auto exact_c) {
   constexpr bool EXACT = decltype(exact_c)::value;
 #pragma unroll
@@ -433,8 +445,18 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #elif TSD_ATTN_ABL & 64 // ablation: neither the DMA wait nor the barrier
 #else
+    const bool check = !EXACT && ONES_ROW && (t % CHECK_EVERY) == CHECK_EVERY - 1 && t + 1 < ntiles;  // uniform
+    if constexpr (!EXACT && ONES_ROW) {
+      if (check) {
+        bool over = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) over = over || !(o[qb][L_BLK][L_REG] < 1.0e37f);  // inf / NaN (the hi = 1 lanes hold a pad row: 0, or NaN next to an inf P)
+        if (__any(over) && lane == 0) *(volatile int*)(smem + FLAG_OFF) = 1;
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (check && *(volatile int*)(smem + FLAG_OFF) != 0) break;  // every wave reads the same word behind the same barrier
 #endif
   }
   };
@@ -513,7 +535,7 @@ extern "C" int tsd_debug_set_attn_qb(tsd_ctx* ctx, int mode) {
 template <int D, int QB>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
-  constexpr int LDS = 2 * (64 * KPITCH * 16 + DBLK * 32 * 128);
+  constexpr int LDS = 2 * (64 * KPITCH * 16 + DBLK * 32 * 128) + 16;  // + the early-abort flag word
   auto fn = flash_attn_kernel<D, QB>;
   static std::atomic<unsigned long long> attr{0};  // one bit per device
   if (!((attr.load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {

@@ -264,14 +264,25 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
       }
       return;
     }
-    if (SK && tap >= 9) {  // fused 1x1 skip: the output pixel itself in A1 / A2 (stride 1, same resolution: checked by the host)
-      const unsigned ld = k_lda1 + (k_dlda2 & (tap == 9 ? 0u : ~0u));
+    // One loop for the nine taps and for the fused 1x1 skip "taps" 9 / 10 (the output pixel itself in A1 / A2; stride 1, same resolution:
+    // checked by the host), the variants picked by selects.  Written as two loops under `if (tap >= 9)` hipcc merged their tails and
+    // indexed a_off1[] through a register: the three 16-byte offset tables of the N = 128 fused-skip kernels moved to scratch (48 B per
+    // lane, csrc/isa_contract.json) and dispatch() had to avoid the 128x128 tile for the VAE's 256 -> 128 residual block.
+    const bool skip = SK && tap >= 9;  // wave-uniform
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int dy = skip ? p.pad : kh, dx = skip ? p.pad : kw;
+    const bool ups = !skip && p.ups;
+    const int Heff = ups ? 2 * p.Hs : p.Hs, Weff = ups ? 2 * p.Ws : p.Ws;
+    const unsigned ld = skip ? k_lda1 + (k_dlda2 & (tap == 9 ? 0u : ~0u)) : (unsigned)p.lda0;
 #pragma unroll
-      for (int i = 0; i < A_PW; i++) {
-        const int iy = (int)(a_pk[i] & 2047u) - 1 + p.pad, ix = (int)((a_pk[i] >> 11) & 2047u) - 1 + p.pad;
-        const unsigned b = a_pk[i] >> 22;
-        a_off1[i] = b != 1023u ? ((unsigned)(((int)b * p.Hs + iy) * p.Ws + ix) * ld + cch * 8) * 2 : PAD_OFF;
-      }
+    for (int i = 0; i < A_PW; i++) {
+      const int iy = (int)(a_pk[i] & 2047u) - 1 + dy, ix = (int)((a_pk[i] >> 11) & 2047u) - 1 + dx;
+      const unsigned b = a_pk[i] >> 22;
+      const bool ok = b != 1023u && (skip || ((unsigned)iy < (unsigned)Heff && (unsigned)ix < (unsigned)Weff));
+      const int sy = ups ? iy >> 1 : iy, sx = ups ? ix >> 1 : ix;
+      a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + sy) * p.Ws + sx) * ld + cch * 8) * 2 : PAD_OFF;
+    }
+    if (skip) {
 #pragma unroll
       for (int i = 0; i < W_PW; i++) {  // the skip weights have their own row pitch
         const int rho = (iw + i * NI) * 8 + lrow;
@@ -280,17 +291,6 @@ __global__ __launch_bounds__((WGM * WGN + LW) * 64, LW ? (WGM * WGN + LW) / 4 : 
         if (n >= p.N) n = p.N - 1;
         w_off[i] = ((unsigned)n * k_ldw1 + cch * 8) * 2;
       }
-      return;
-    }
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int Heff = p.ups ? 2 * p.Hs : p.Hs, Weff = p.ups ? 2 * p.Ws : p.Ws;
-#pragma unroll
-    for (int i = 0; i < A_PW; i++) {
-      const int iy = (int)(a_pk[i] & 2047u) - 1 + kh, ix = (int)((a_pk[i] >> 11) & 2047u) - 1 + kw;
-      const unsigned b = a_pk[i] >> 22;
-      const bool ok = b != 1023u && (unsigned)iy < (unsigned)Heff && (unsigned)ix < (unsigned)Weff;
-      const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
-      a_off1[i] = ok ? ((unsigned)(((int)b * p.Hs + sy) * p.Ws + sx) * (unsigned)p.lda0 + cch * 8) * 2 : PAD_OFF;
     }
   };
   if constexpr (CONV) { if (issuer) conv_tap_ptrs(st_tap); }
@@ -1379,9 +1379,10 @@ static int dispatch(tsd_ctx* ctx, const GemmK& k, int batch) {
   // halo-x measured: -3...5 % on the 128x128-tile convs of the VAE (N = 128 / 256 / 512), nothing on the 128x160 ones (TSD_CONV_HALO=2 turns those on too)
   // (the halo-x K order addresses W row-major: a launch that reads the K-tile-major weight copy keeps its plain tile)
   if (CONV && force_cfg < 0 && k.w_kts == 128u && hx_eligible(o, k) && (id == 2 || (id == 0 && o.conv_halo >= 2))) id += 30;
-  // the fused-skip variant of the 128x128 two-blocks-per-CU tile spills (48 B of scratch per lane); its 64-row sibling does not: the
-  // decoder's 256 -> 128 residual block at 512 x 512 (K = 1152 + 256) runs 1.18 ms instead of 1.35 (in-step sweep), same bits
-  if (CONV && force_cfg < 0 && k.Cin1 > 0 && id == 2) id = 3;
+  // rounds 3-4: the fused-skip variant of the 128x128 two-blocks-per-CU tile kept its offset tables in scratch (48 B per lane) and the
+  // decoder's 256 -> 128 residual block at 512 x 512 (K = 1152 + 256) ran its 64-row sibling instead (1.18 ms against 1.35).  Round 5:
+  // the scratch is gone (conv_tap_ptrs); TSD_GEMM_SKIP128=0 restores the detour for A/B runs
+  if (CONV && force_cfg < 0 && k.Cin1 > 0 && id == 2 && !o.skip128) id = 3;
   if ((id == 30 || id == 32) && !(CONV && hx_shape_ok(k) && k.w_kts == 128u)) TSD_FAIL(TSD_E_ARG, "gemm: halo-x tile configuration %d on an ineligible problem", id);
   return launch_by_id<CONV>(ctx, k, batch, id);
 }

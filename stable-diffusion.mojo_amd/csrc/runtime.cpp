@@ -40,6 +40,7 @@ void options_from_env(TsdOptions& o) {
   o.sk_cfg = env_int("TSD_GEMM_SK_CFG", o.sk_cfg);
   o.sk256 = env_int("TSD_GEMM_SK256", o.sk256);
   o.thin_cfg = env_int("TSD_GEMM_THIN_CFG", o.thin_cfg);
+  o.skip128 = env_int("TSD_GEMM_SKIP128", o.skip128);
   o.tune = env_int("TSD_GEMM_TUNE", o.tune);
   if (const char* ov = getenv("TSD_GEMM_CFG_OVERRIDE")) { strncpy(o.cfg_override, ov, sizeof(o.cfg_override) - 1); o.cfg_override[sizeof(o.cfg_override) - 1] = 0; }
   o.gn_apply_mult = env_int("TSD_GN_APPLY_MULT", o.gn_apply_mult);

@@ -13,12 +13,15 @@ shipped object was assembled from.  Source-written waits sit between `;;#ASMSTAR
 
 Checks, per kernel, on the control-flow graph rebuilt from the labels and branches of the listing:
   R0  the immediate equals D + E, and D is a whole number of tiles (x*P + y*P2);
-  R1  on EVERY path into a counted wait, the N youngest vector-memory instructions (those it leaves in flight) contain no
-      store and at least E plain loads - otherwise more than D LDS-DMA instructions stay in flight, i.e. pieces of the tile
-      the wait is for (the round-4 bug: 17 loads where E said 25);
+  R1  on EVERY path into a counted wait, at most D of the N youngest vector-memory instructions (those it leaves in flight) are
+      LDS-DMA instructions - otherwise pieces of the tile the wait is for stay in flight (the round-4 bug: 17 plain loads
+      where E said 25, so 23 DMA pieces instead of 15).  Extra loads or stores in the window only make a wait stricter
+      (gfx9 counts loads and stores in one in-order counter);
   R2  between a counted wait and the source wait before it (any path) the wave issues whole tiles: the number of LDS-DMA
       instructions is x*P + y*P2 - a merged, dropped or duplicated DMA instruction breaks this;
-  R3  no indirect branch in a kernel with counted waits (the graph would be incomplete);
+  R3  no indirect branch in a kernel with counted waits (the graph would be incomplete); between the `tsd-wait-alt begin / end`
+      markers of an if / else chain of waits (exactly one executes - hipcc lowers the chain to independent skips a graph walk
+      could bypass, so the end marker counts as "a source wait has executed") there are source waits only, on every path;
   R4  the kernel's figures - vector-memory instruction counts, source / compiler-inserted vmcnt waits, registers, spills,
       scratch bytes, and per counted wait the set of window and interval compositions found - equal the committed table
       csrc/isa_contract.json.  Any drift fails until a person re-blesses the table (`--update`), which by the rules of
