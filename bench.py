@@ -136,7 +136,7 @@ def pmc_traffic_per_gemm_launch():
     with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads -> x2).
     (None, None) when no profile is committed: bench.py itself never runs a profiler, so the figure is NOT measured by
     this run - `traffic_source` in the JSON line says which file it came from."""
-    for name in ("r04_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
+    for name in ("r05_pmc_hbm_traffic.txt", "r04_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             fetch = write = launches = 0.0
