@@ -13,7 +13,7 @@
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; O=$R/gpurun_out/r05f; mkdir -p $O
 cd $R; export TMPDIR=/tmp HIP_FORCE_DEV_KERNARG=1
-timeout 2400 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
+TSD_JITTER_LOOPS=600 timeout 2400 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
 grep "\[parity\]" $O/pytest_gpu.log > $O/parity.log; tail -1 $O/pytest_gpu.log >> $O/parity.log
 timeout 900 python bench.py --steps 50 --warmup 10 > $O/bench.json 2> $O/bench.err
 (python scripts/kloop_probe.py "51,11,5,45,0,54" conv; python scripts/kloop_probe.py "54,11,51,5,7,47,1" dense) > $O/kloop_probe.txt 2>&1
