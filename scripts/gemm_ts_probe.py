@@ -1,3 +1,5 @@
+"""Per-block phase timestamps of a few GEMM launches on a -DTSD_GEMM_TS build (make BUILD=build_ts OUT=../lib/libtsd_ts.so EXTRA=-DTSD_GEMM_TS):
+   TSD_LIB=$PWD/stable-diffusion.mojo_amd/lib/libtsd_ts.so python scripts/gemm_ts_probe.py      (profiles/r05_gemm_ts.txt)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"), "stable-diffusion.mojo_amd"))
 os.environ["TSD_BENCH_EPI"]="1"; os.environ["TSD_GEMM_TS"]="1"

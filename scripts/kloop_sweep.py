@@ -1,3 +1,5 @@
+"""K sweep of one conv problem (C -> 320 at 64 x 64, batch 8: M = 32768) over tile configurations: launch time at eight K lengths
+(profiles/README.md round 5: T = 14.5 + 1.0 x K-tiles us for cfg 51 - every tile runs ~1.3 PF inside its K loop).  python scripts/kloop_sweep.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"), "stable-diffusion.mojo_amd"))
 os.environ.setdefault("TSD_BENCH_EPI", "1")
