@@ -102,7 +102,10 @@ def test_attention_exact_pass_runs_only_when_a_row_overflows(gpu_ctx, tsd_mod):
     assert L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1) >= 0
     for name, expect_exact in (("self_attention_d40", False), ("self_attention_d40_falling_scores", False),
                                ("self_attention_d40_rising_scores", True), ("self_attention_d80_rising_scores", True),
-                               ("self_attention_d160_rising_scores", True)):
+                               ("self_attention_d160_rising_scores", True),
+                               # key loops of 17 - 18 tiles: the early look (every eighth tile) and the final check both lead to the exact pass
+                               ("self_attention_d40_long_rising", True), ("self_attention_d40_spike_tile14", True),
+                               ("self_attention_d40_spike_last_tile", True), ("self_attention_d80_long_rising", True)):
         c = CASES[name]
         i = c.build()
         y = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
