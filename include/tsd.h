@@ -316,8 +316,9 @@ int tsd_debug_attn_bench(tsd_ctx* ctx, int B, int H, int d, int Sq, int Sk, int 
  * workgroup exactly when one of its rows overflowed fp16: number of workgroups that repeated since the last reset
  * (reset != 0 clears the counter); < 0 on error.  Synchronises the context's stream. */
 int tsd_debug_attn_exact_passes(tsd_ctx* ctx, int reset);
-/* Query blocks per wave of the d = 40 attention core: 0 = chosen by shape (default), 1 = 32 queries per wave, 2 = 64.
- * Both compute every row with the same instruction sequence: bitwise equal results as long as no workgroup takes the exact
+/* Kernel of the d = 40 attention core: 0 = chosen by shape (default), 1 = 32 queries per wave, 2 = 64 (4-wave workgroups),
+ * 3 = the 8-wave two-group kernel (64 queries per wave, 512 per workgroup).
+ * All compute every row with the same instruction sequence: bitwise equal results as long as no workgroup takes the exact
  * repeat (there the repeat and the reference moves are decided per workgroup / per wave, i.e. over different row sets).  The
  * default choice depends on the layer shape only, never on the batch.  Returns the previous mode. */
 int tsd_debug_set_attn_qb(tsd_ctx* ctx, int mode);

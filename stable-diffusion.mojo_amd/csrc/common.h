@@ -62,7 +62,9 @@ struct TsdOptions {
   int conv_w_tm_mib = 2, lin_w_tm = 1, lin_w_tm_kib = 1024;  // TSD_CONV_W_TM, TSD_LIN_W_TM, TSD_LIN_W_TM_KIB
   // flash attention (kernels_attn.hip)
   int attn_qb = 2;         // TSD_ATTN_QB: d = 40, 32-query blocks per wave where the key loop is long
-  int attn_qb_force = 0;   // tsd_debug_set_attn_qb: 0 = by shape, 1 / 2 = always
+  int attn_qb_force = 0;   // tsd_debug_set_attn_qb: 0 = by shape, 1 / 2 = always (4-wave workgroups), 3 = always the 8-wave kernel
+  int attn_wg8 = 1;        // TSD_ATTN_WG8: d = 40 long key loops on the 8-wave two-group kernel (kernels_attn8.hip)
+  int attn8_var = 0;       // TSD_ATTN8_VAR: timing / A-B variant of that kernel (builds with -DTSD_ATTN8_VARIANTS only)
   int attn_diag = 1;       // tsd_debug_set_attn_diag: second optimistic reference (the query's own key block)
   int attn_xcd = 0;        // TSD_ATTN_XCD: XCD-aware (head, query tile) map
   // GEMM / conv dispatch (kernels_gemm.hip)

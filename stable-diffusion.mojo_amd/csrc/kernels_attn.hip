@@ -34,8 +34,7 @@
 #include <type_traits>
 #include <atomic>
 
-#include "common.h"
-#include "lds_dma.h"
+#include "attn_common.h"
 
 // Ablation builds of the attention core (timing only, results wrong): bit 0 no exponentials, bit 1 no P.V MFMAs, bit 2 no
 // QK^T MFMAs, bit 3 s_setprio(1) around the QK^T MFMAs, bit 4 s_setprio(1) around the P.V / exponential region, bit 5 no per-tile
@@ -43,26 +42,6 @@
 #ifndef TSD_ATTN_ABL
 #define TSD_ATTN_ABL 0
 #endif
-#ifndef TSD_ATTN_CHECK_EVERY
-#define TSD_ATTN_CHECK_EVERY 8  // key tiles between two looks at the row sums in the optimistic softmax pass (early abort, below)
-#endif
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-struct AttnK {
-  const half_t* Q; const half_t* K; const half_t* Vt; half_t* O; const half_t* zeros; const half_t* ones;
-  long long sQ, sK, sVt, sO;
-  int ldq, ldk, ldvt, ldo;
-  int H, Sq, Sk, Skv;  // Skv: number of valid V^T columns (Sk rounded up to 8)
-  float c;             // scale * log2(e)
-  int diag;            // self-attention (Sq == Sk): the optimistic reference also covers each query's own 32-key block
-  int xcd_map;         // 1: (head, query tile) remapped so that every XCD (dispatch id % 8) owns whole heads - its L2 then pulls a head's
-                       // K / V^T once instead of every XCD pulling every head's (needs B*H % 8 == 0)
-  int* exact_ctr;      // the context's count of workgroups that had to run the exact pass (tsd_debug_attn_exact_passes)
-};
 
 __device__ __forceinline__ void glds16a(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -72,20 +51,10 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 #ifdef TSD_ATTN_TS
 __device__ unsigned long long g_attn_ts[4 * 65536];  // per block: memtime start/end, memrealtime start/end
 #endif
-// Largest score (log2 units, relative to the running reference) a tile may reach before the reference is moved.
-// P = exp2(s - ref) is then at most 2^12 - far inside fp16 (65504) and harmless for the fp32 O / row-sum accumulators.
-#define TSD_ATTN_LAZY 12.0f
-// Optimistic pass: ref = (row maximum of tile 0) + this, so a later score may exceed tile 0's maximum by 16 + 4 = 20 log2 units
-// (13.9 nats) before an fp16 P overflows and the exact pass has to run; the largest P of tile 0 is then 2^-4, still 2^10
-// above the smallest normal fp16.
-#define TSD_ATTN_HEADROOM 4.0f
-
 // QB = 32-query blocks per wave.  Every K / V^T fragment read from LDS feeds QB MFMAs, and the LDS pipe is what bounds
 // QB = 1: one 1-KiB ds_read_b128 per 32x32x16 MFMA is 8 LDS cycles per 32 matrix-pipe cycles on each of 4 SIMDs - the
 // CU's whole LDS bandwidth, before the tile DMA writes.  QB = 2 (d = 40: 64 queries per wave, 256 per workgroup) halves
 // that at the price of 2 waves per SIMD instead of 4.
-// An (empty) use of a 16-register block.  A device function, so the host pass never sees the "v" constraint.
-__device__ __forceinline__ void keep_alive(const f16v& v) { asm volatile("" ::"v"(v)); }
 
 template <int D, int QB>
 __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kernel(const AttnK p) {
@@ -525,12 +494,13 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
 
 bool attn_fused_supported(int d) { return d == 40 || d == 80 || d == 160; }
 // per-context switches (TsdOptions): attn_diag 0 = optimistic reference from key tile 0 only (the round-2 behaviour);
-// attn_qb_force 0 = 32- / 64-query waves chosen by the layer shape, 1 / 2 = that many query blocks per wave whenever d = 40
+// attn_qb_force 0 = kernel chosen by the layer shape, 1 / 2 = that many query blocks per wave (4-wave workgroups) whenever d = 40,
+// 3 = the 8-wave two-group kernel whenever d = 40
 extern "C" int tsd_debug_set_attn_diag(tsd_ctx* ctx, int on) {
   return ctx_set_option(ctx, &TsdOptions::attn_diag, on, 0, 1);
 }
 extern "C" int tsd_debug_set_attn_qb(tsd_ctx* ctx, int mode) {
-  return ctx_set_option(ctx, &TsdOptions::attn_qb_force, mode, 0, 2);
+  return ctx_set_option(ctx, &TsdOptions::attn_qb_force, mode, 0, 3);
 }
 template <int D, int QB>
 static int launch_fa(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
@@ -573,6 +543,9 @@ int launch_flash_attention(tsd_ctx* ctx, const AttnArgs& a) {
       // The choice keys on the layer (Sq, Sk, H), never on the batch: the two variants are bitwise equal only while no
       // workgroup repeats exactly (the repeat is decided per 128- / 256-query workgroup and moves the reference per 32 / 64
       // rows), so a sample computed alone must run the same variant as its row of a batch (bitwise batch invariance).
+      // Eight waves in two staggered groups (kernels_attn8.hip) for the long key loops of a big grid - the 64x64 level's 4096 x 4096 call
+      if (ctx->opt.attn_qb_force ? ctx->opt.attn_qb_force == 3 : (ctx->opt.attn_wg8 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 512) * a.H >= 64))
+        return launch_flash_attention8(ctx, k, a.B, a.H, a.Sq, a.d, ctx->opt.attn8_var);
       if (ctx->opt.attn_qb_force ? ctx->opt.attn_qb_force == 2 : (ctx->opt.attn_qb == 2 && a.Sk >= 512 && (long long)ceil_div(a.Sq, 256) * a.H >= 64))
         return launch_fa<40, 2>(ctx, k, a.B, a.H, a.Sq);
       return launch_fa<40, 1>(ctx, k, a.B, a.H, a.Sq);

@@ -28,6 +28,8 @@ void options_from_env(TsdOptions& o) {
   o.lin_w_tm_kib = env_int("TSD_LIN_W_TM_KIB", o.lin_w_tm_kib);
   { const int q = env_int("TSD_ATTN_QB", o.attn_qb); if (q == 1 || q == 2) o.attn_qb = q; }
   o.attn_xcd = env_int("TSD_ATTN_XCD", o.attn_xcd);
+  o.attn_wg8 = env_int("TSD_ATTN_WG8", o.attn_wg8) ? 1 : 0;
+  o.attn8_var = env_int("TSD_ATTN8_VAR", o.attn8_var);
   o.xcdn = env_int("TSD_GEMM_XCDN", o.xcdn);
   o.conv_halo = env_int("TSD_CONV_HALO", o.conv_halo);
   o.splitk = env_int("TSD_GEMM_SPLITK", o.splitk);

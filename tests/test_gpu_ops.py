@@ -236,6 +236,43 @@ def test_attention_64_queries_per_wave_is_bitwise_the_128_query_workgroup(gpu_ct
         L.tsd_debug_set_attn_qb(gpu_ctx.h, prev)
 
 
+def test_attention_8wave_two_group_kernel_matches_the_oracle_and_the_4wave_kernel(gpu_ctx, tsd_mod):
+    """flash_attn8_kernel<40> (kernels_attn8.hip: eight waves, two groups one phase apart, 512 queries per workgroup - what the 4096 x 4096
+    call of the 64x64 level runs) forced onto every d = 40 case, ragged lengths, partial last tiles, key loops of 1 - 18 tiles, the
+    cases that must take the exact repeat (early look and final check) and the 77-key cross attention included.  Same products in the
+    same order as flash_attn_kernel<40, 2>, but the softmax reference enters through the QK^T pad column (rounded to 32 x fp16), so the two
+    agree to the fp16 rounding of P rather than bit for bit; each is held to the oracle with the case's own tolerance."""
+    from tsd._lib import lib
+    from util import rel_l2
+    L = lib()
+    prev = L.tsd_debug_set_attn_qb(gpu_ctx.h, 2)
+    L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+    try:
+        for name, expect_exact in (("self_attention_d40", False), ("self_attention_d40_ragged", False), ("self_attention_d40_falling_scores", False),
+                                   ("self_attention_d40_self_peaked", False), ("cross_attention_d40_T77", False),
+                                   ("self_attention_d40_rising_scores", True), ("self_attention_d40_long_rising", True),
+                                   ("self_attention_d40_spike_tile14", True), ("self_attention_d40_spike_last_tile", True)):
+            c = CASES[name]
+            i = c.build()
+            ref = np.asarray(c.oracle(i), dtype=np.float32)
+            L.tsd_debug_set_attn_qb(gpu_ctx.h, 2)
+            y2 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+            L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+            L.tsd_debug_set_attn_qb(gpu_ctx.h, 3)
+            y8 = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+            n8 = L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+            y8b = np.asarray(c.device(tsd_mod, i), dtype=np.float32)
+            L.tsd_debug_attn_exact_passes(gpu_ctx.h, 1)
+            assert (n8 > 0) == expect_exact, (name, n8)
+            np.testing.assert_array_equal(y8, y8b, err_msg=name + ": two runs of the 8-wave kernel differ")
+            assert_close(y8, ref, c.tol, c.tol_max, what=name + " (8-wave kernel)")
+            d = rel_l2(y8, y2)
+            print(f"[parity] {name}: 8-wave vs 4-wave kernel rel_l2={d:.3e}, exact repeats {n8}")
+            assert d <= 1e-3, (name, d)
+    finally:
+        L.tsd_debug_set_attn_qb(gpu_ctx.h, prev)
+
+
 @pytest.mark.parametrize("B,H,Cin,N,cfg,ref", [(2, 64, 64, 160, 30, 0), (2, 64, 640, 320, 30, 0), (1, 128, 128, 128, 32, 2),
                                                (1, 256, 128, 128, 32, 2), (2, 64, 128, 256, 32, 2)])
 def test_halo_x_conv_order_matches_plain_tiles(gpu_ctx, B, H, Cin, N, cfg, ref):
