@@ -2,23 +2,33 @@
 // kernel of a denoise step) as an EIGHT-wave workgroup whose two halves run one phase apart.
 //
 // Same arithmetic as flash_attn_kernel<40, 2> (kernels_attn.hip; `Self_Attention.forward`, helpers/attention.mojo:30-62): swapped QK^T on
-// v_mfma_f32_32x32x16_f16 with scale*log2(e) folded into Q and -ref as the C operand, optimistic softmax pass with an exact repeat, P
-// consumed from registers as the B operand of O^T = V^T.P^T, row sums from a ones row of V^T.  One arithmetic difference: d = 40 pads the
-// QK^T reduction to 48, and this kernel uses the first pad column for the reference - K column 40 is the constant 32 (never in LDS: the
-// lanes that would read the pad chunk select it), Q column 40 holds -ref/32 - so the scores leave the MFMAs as s - ref WITHOUT a 16-register
-// C operand per query block (32 VGPRs the two-phase schedule needs).  The reference is thereby rounded to fp16 x 32 (any reference gives the
-// same softmax; m_run holds exactly what was subtracted), so results agree with flash_attn_kernel to fp16 rounding of P, not bit for bit.
-// What differs is WHEN a wave does what:
+// v_mfma_f32_32x32x16_f16 with scale*log2(e) folded into Q, optimistic softmax pass with an exact repeat, P consumed from registers as the B
+// operand of O^T = V^T.P^T, row sums from a ones row of V^T; every accumulator sees the same products in the same order.  One arithmetic
+// difference: d = 40 pads the QK^T reduction to 48, and this kernel uses the first pad column for the softmax reference - K column 40 is the
+// constant 32 (a 16-byte block per ring slot that the pad chunk's lanes read), Q column 40 holds -ref/32 - so the scores leave the MFMAs as
+// s - ref WITHOUT a 16-register C operand per query block (32 VGPRs the schedule below needs).  The reference is thereby rounded to 32 x fp16
+// (any reference gives the same softmax; m_run holds exactly what was subtracted), so the results agree with flash_attn_kernel to the fp16
+// rounding of P, not bit for bit.
 //
-//   * flash_attn_kernel runs two 4-wave workgroups per CU: the two waves of a SIMD are not coordinated, both interleave MFMAs with their own
-//     exponentials / converts / fragment reads, and the matrix pipe ends up 52-55 % busy (profiles/r05_pmc_sq.txt) - MFMA time and the rest add.
-//   * here a wave alternates between an X phase (no MFMA: V^T fragment reads of key tile t, the 64 exponentials + 32 converts that turn the
-//     scores S(t) into P(t), this wave's LDS-DMA pieces of tile t+2) and an M phase (28 MFMAs from registers: P(t).V(t), then K(t+1).Q^T; the six K
-//     fragment reads ride in its shadow).  Waves 0-3 and 4-7 sit pairwise on the four SIMDs and run the phases in opposition under two
-//     s_barrier per tile: while one wave of a SIMD feeds the matrix pipe its partner does the VALU / LDS / DMA work
-//     (MI355X_MICROARCH.md "Two waves per SIMD": pair matrix with memory, one static s_setprio for the younger half, no per-segment flips).
-//   * all eight waves share each K / V^T tile (512 queries per workgroup: half the LDS-DMA per query); 3-slot ring, group 0 issues the five
-//     1-KiB DMA instructions of a K tile, group 1 those of a V^T tile (one per wave, a second one on each group's first wave) behind counted waits.
+// What the schedule is built on (scripts/micro/valu_port.hip, profiles/r06_valu_port*.txt - the two waves of a SIMD, shader clocks):
+//   * MFMAs and VALU work do not overlap by themselves.  28 MFMAs take 960 clocks, 64 v_exp_f32 + 32 v_cvt_pk_f16_f32 620; one wave doing both
+//     takes the sum (1260 with half of the VALU work), two waves doing both side by side take 2390 for twice the work: a wave whose next
+//     instruction is an MFMA waiting for the matrix pipe keeps the SIMD's VALU issue.  That - not LDS reads, DMA or the barrier - is why
+//     flash_attn_kernel's matrix pipe is 52-55 % busy (profiles/r05_pmc_sq.txt): its two waves per SIMD serialise.
+//   * A partner's VALU work does hide behind a wave's MFMAs when that wave drops to priority 0 for one instruction behind every MFMA
+//     (s_setprio 0 ; s_setprio 1): 28 MFMAs + the partner's 64 exp + 32 cvt in 1190 clocks, whichever wave is older; the flip costs the MFMA
+//     chain ~10 clocks each.  A wave's OWN VALU work between its MFMAs always adds.
+// So a wave alternates between
+//   * an X phase (no MFMA): this wave's LDS-DMA pieces of key tile t+2, the eight V^T fragment reads of tile t, the exponentials + converts
+//     that turn query block 0's scores S(t) into P(t), and
+//   * an M phase (28 MFMAs, priority 1 with a flip behind each): per query block P(t).V(t) (8) then K(t+1).Q^T (6); query block 1's
+//     exponentials ride between the first eighteen MFMAs (a split found by measurement: all 64 in the X phase make it the longer phase),
+//     the six K(t+1) fragment reads go out behind the first MFMA,
+// and waves 0-3 / 4-7, which sit pairwise on the four SIMDs, run the two phases in opposition under two s_barrier per tile.  All eight waves
+// share each K / V^T tile (512 queries per workgroup: half the LDS-DMA per query of the 4-wave kernel); 3-slot ring; group 0 issues the five
+// 1-KiB DMA instructions of a K tile, group 1 those of a V^T tile (one per wave, a second one on each group's first wave) behind counted waits.
+// Measured (profiles/r06_attn8_*.txt): 4096 x 4096, B*H = 64: 2590 clocks per key tile and SIMD against 3230 for flash_attn_kernel<40, 2>;
+// 6 % less time on the same box (the chip gives part of the cycle saving back as clock).
 //
 // Ring protocol (h = half periods; group 0: X(t) at h = 2t, M(t) at 2t+1; group 1: X(t) at 2t+1, M(t) at 2t+2):
 //   K(t+2) is issued by group 0 at the start of X(t), waited for (counted: the pieces of tile t+3 stay in flight) at the end of X(t+1),
@@ -34,8 +44,12 @@
 
 #include "attn_common.h"
 
-// variant bits (timing / A-B builds; 0 ships): 1 = static s_setprio(1) for waves 4-7, 2 = s_setprio(1) around every M phase,
-// 4 = no exponentials (timing only), 8 = no MFMAs (timing only), 16 = K fragment reads at the start of the M phase
+// variant bits (timing / A-B builds, -DTSD_ATTN8_VARIANTS): 1 = static s_setprio(1) for waves 4-7, 2 = s_setprio(1) around every M phase,
+// 4 = no exponentials (timing only), 8 = no MFMAs (timing only), 16 x n = n of query block 1's four chunks exponentiated in the X phase,
+// 128 = priority flip behind every MFMA of the M phase, 256 = V^T fragment reads at the start of the X phase
+#ifndef TSD_ATTN8_DEFAULT_VAR
+#define TSD_ATTN8_DEFAULT_VAR 384  // shipped: priority flips in the M phase + V^T fragments at the start of the X phase
+#endif
 #ifdef TSD_ATTN8_TS
 __device__ unsigned long long g_attn8_ts[256 * 8 * 4];  // per (block < 256, wave): ticks in X, at barrier 1, in M, at barrier 2
 #endif
@@ -44,9 +58,13 @@ template <int D, int VAR>
 __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
   static_assert(D == 40, "the 8-wave kernel is built for d = 40 (5 + 5 DMA pieces per tile split evenly over 4 + 4 waves)");
   constexpr int QB = 2, NB = 3;
+  constexpr int XCH = (VAR >> 4) & 7;  // chunks (of 4) of query block 1 exponentiated in the X phase; the others between the M phase's MFMAs
+  static_assert(XCH <= 4, "variant");
+  constexpr bool VF_EARLY = (VAR & 256) != 0;  // V^T fragment reads at the start of the X phase instead of behind the exponentials
+  constexpr bool FLIP = (VAR & 128) != 0;  // priority 1 in the M phase, dropped for one instruction behind every MFMA
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1);
   constexpr int DBLK = (D + 31) / 32, VROWS = DBLK * 32;
-  constexpr int K_BYTES = 64 * KPITCH * 16, V_BYTES = VROWS * 128, BUF_BYTES = K_BYTES + V_BYTES;
+  constexpr int K_BYTES = 64 * KPITCH * 16, V_BYTES = VROWS * 128, KPAD_OFF = K_BYTES + V_BYTES, BUF_BYTES = KPAD_OFF + 16;  // slot: K tile, V^T tile, the K pad chunk
   constexpr int FLAG_OFF = NB * BUF_BYTES;
   constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3);  // accumulator holding row D = the row sums (lanes hi = 0)
   static_assert(VROWS > D && (((D % 32) >> 2) & 1) == 0, "ones row in the hi = 0 half");
@@ -128,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
     const half_t fill = R == D ? (half_t)1.f : (half_t)0.f;
     *(h8*)(smem + buf * BUF_BYTES + K_BYTES + R * 128 + pos * 16) = h8{fill, fill, fill, fill, fill, fill, fill, fill};
   }
+  if (tid < NB) *(h8*)(smem + tid * BUF_BYTES + KPAD_OFF) = h8{(half_t)32.f, 0, 0, 0, 0, 0, 0, 0};  // K chunk 5 of every key: column 40 = 32 (REF_UNIT), 41..47 = 0
   // "some row of this workgroup overflowed" (early abort); an LDS-typed pointer: a volatile access through the generic one becomes a flat load
   volatile __attribute__((address_space(3))) int* const flag = (volatile __attribute__((address_space(3))) int*)(smem + FLAG_OFF);
   if (tid == 0) *flag = 0;  // published by run()'s first barrier
@@ -201,27 +220,22 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
     __syncthreads();
 
     // S^T(t) - ref = K(t) . Q^T + (-ref): two 32-key blocks per query block, the six K fragments read once
+    // the six K fragments of a tile; in the last k-step the hi = 1 lanes hold the pad chunk (columns 40..47): they read the slot's constant block
     auto k_frags = [&](int buf, h8 (&kf)[KSTEPS][2]) {
       const char* sK = smem + buf * BUF_BYTES;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        const int ch = ks * 2 + hi < DCH ? ks * 2 + hi : DCH - 1;  // the pad chunk's lanes read chunk 4 (in range); qk() replaces it
-        kf[ks][0] = *(const h8*)(sK + ((l31)*KPITCH + ch) * 16);
-        kf[ks][1] = *(const h8*)(sK + ((32 + l31) * KPITCH + ch) * 16);
+        const bool pad = ks * 2 + 1 >= DCH;
+        kf[ks][0] = *(const h8*)(sK + ((pad && hi) ? KPAD_OFF : ((l31)*KPITCH + ks * 2 + hi) * 16));
+        kf[ks][1] = *(const h8*)(sK + ((pad && hi) ? KPAD_OFF : ((32 + l31) * KPITCH + ks * 2 + hi) * 16));
       }
     };
-    auto qk = [&](h8 (&kf)[KSTEPS][2]) {
+    auto qk = [&](const h8 (&kf)[KSTEPS][2]) {
       f16v z;
 #pragma unroll
       for (int r = 0; r < 16; r++) z[r] = 0.f;
-      const h8 kpad = h8{(half_t)REF_UNIT, 0, 0, 0, 0, 0, 0, 0};  // K chunk 5: column 40 = 32, columns 41..47 = 0
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        if (ks * 2 + 1 >= DCH) {  // the last k-step: its selects (and the wait for its fragment reads) sit behind the MFMAs of the others
-          __builtin_amdgcn_sched_barrier(0);
-          kf[ks][0] = hi ? kpad : kf[ks][0];
-          kf[ks][1] = hi ? kpad : kf[ks][1];
-        }
 #pragma unroll
         for (int qb = 0; qb < QB; qb++) {
           if constexpr (VAR & 8) {
@@ -312,43 +326,48 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
       constexpr bool LIVE = decltype(live_c)::value;  // tile t + 2 exists
       constexpr bool MORE = decltype(more_c)::value;  // tile t + 1 exists
       const int nx1 = cur == NB - 1 ? 0 : cur + 1, nx2 = cur == 0 ? NB - 1 : cur - 1;  // slots of tiles t + 1, t + 2
-      // ---------------- X(t): no MFMA.  DMA pieces of tile t + 2, V^T fragments of tile t, S(t) -> P(t) ----------------
+      // ---------------- X(t): no MFMA.  DMA pieces of tile t + 2, S(t) -> P(t) for query block 0, V^T fragments of tile t ----------------
       tsd_jitter();
       if constexpr (LIVE) stage(t + 2, nx2);
-      if (t > 0) {
-        mask_tail(t);
-        if constexpr (EXACT) reference(t);
-      }
-#pragma unroll
-      for (int qb = 0; qb < QB; qb++)
-#pragma unroll
-        for (int kq = 0; kq < 4; kq++) {
-          const int kb = kq >> 1, r0 = (kq & 1) * 8;
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            float p0, p1;
-            if constexpr (VAR & 4) { p0 = s[qb][kb][r0 + e] * 0.001f; p1 = s[qb][kb][r0 + e + 1] * 0.001f; }
-            else { p0 = __builtin_amdgcn_exp2f(s[qb][kb][r0 + e]); p1 = __builtin_amdgcn_exp2f(s[qb][kb][r0 + e + 1]); }
-            pf[qb][kq][e] = (half_t)p0;
-            pf[qb][kq][e + 1] = (half_t)p1;
-          }
-        }
-      // P(t) is complete in front of barrier 1: without the (empty) uses hipcc sinks half of the exponentials into the M phase
-#pragma unroll
-      for (int qb = 0; qb < QB; qb++)
-#pragma unroll
-        for (int kq = 0; kq < 4; kq++) asm volatile("" : "+v"(pf[qb][kq]));
-      __builtin_amdgcn_sched_barrier(0);
-      {  // the V^T fragments of tile t, once the scores are dead (register budget: 256 per wave)
+      auto v_frags = [&]() {  // the eight V^T fragments of tile t
         const char* sV = smem + cur * BUF_BYTES + K_BYTES;
 #pragma unroll
         for (int kq = 0; kq < 4; kq++)
 #pragma unroll
           for (int d = 0; d < DBLK; d++) vf[kq][d] = *(const h8*)(sV + (d * 32 + l31) * 128 + (((kq * 2 + hi) ^ vkey) << 4));
+      };
+      if constexpr (VF_EARLY) { v_frags(); __builtin_amdgcn_sched_barrier(0); }  // in front of the exponentials: their LDS latency hides under them
+      if (t > 0) {
+        mask_tail(t);
+        if constexpr (EXACT) reference(t);
       }
+      // one pair of probabilities: two exponentials and one packed convert.  A lone wave issues a v_exp_f32 every ~16 clocks (measured: 64 of
+      // them back to back made the X phase 1300+ clocks against 900 of MFMAs in the partner's M phase), so only query block 0 (+ XCH chunks
+      // of block 1) is exponentiated here; the rest rides between the MFMAs of this wave's own M phase.
+      auto p_pair = [&](int qb, int pr) {  // pr = 0..15: chunk kq = pr / 4, elements 2 * (pr % 4), + 1
+        const int kq = pr >> 2, e = (pr & 3) * 2, kb = kq >> 1, r0 = (kq & 1) * 8;
+        float p0, p1;
+        if constexpr (VAR & 4) { p0 = s[qb][kb][r0 + e] * 0.001f; p1 = s[qb][kb][r0 + e + 1] * 0.001f; }
+        else { p0 = __builtin_amdgcn_exp2f(s[qb][kb][r0 + e]); p1 = __builtin_amdgcn_exp2f(s[qb][kb][r0 + e + 1]); }
+        pf[qb][kq][e] = (half_t)p0;
+        pf[qb][kq][e + 1] = (half_t)p1;
+      };
+      constexpr int XP = 4 * XCH;  // pairs of query block 1 done in the X phase
+#pragma unroll
+      for (int pr = 0; pr < 16; pr++) p_pair(0, pr);
+#pragma unroll
+      for (int pr = 0; pr < XP; pr++) p_pair(1, pr);
+      // complete in front of barrier 1: without the (empty) uses hipcc sinks exponentials into the M phase
+#pragma unroll
+      for (int kq = 0; kq < 4; kq++) asm volatile("" : "+v"(pf[0][kq]));
+#pragma unroll
+      for (int kq = 0; kq < XCH; kq++) asm volatile("" : "+v"(pf[1][kq]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!VF_EARLY) v_frags();
       // early abort: the row sum (row D of O^T, tiles < t) is infinite from an overflowing tile on.  Every CHECK_EVERY-th tile each wave looks
       // at it and raises the flag in front of barrier 1; every wave reads it behind ITS barrier 2 of the same tile - by then both groups'
-      // looks at tile t are behind a barrier, and the next look is eight tiles away: all waves take the same decision.
+      // looks at tile t are behind a barrier, and the next look is eight tiles away: all waves take the same decision.  (The exact pass never
+      // consults the flag: `check` is false there.)
       const bool check = !EXACT && (t % CHECK_EVERY) == CHECK_EVERY - 1 && t + 1 < ntiles;  // uniform
       if constexpr (!EXACT) {
         if (check) {
@@ -373,30 +392,48 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       TS8(ts_b1, ts0);
-      // ---------------- M(t): 28 MFMAs from registers.  O^T += V^T(t).P^T(t), then S^T(t+1) = K(t+1).Q^T - ref ----------------
+      // ---------------- M(t): 28 MFMAs.  Per query block: O^T += V^T(t).P^T(t) (8), then S^T(t+1) = K(t+1).Q^T - ref (6) ----------------
+      // slots 0-7 P.V of block 0, 8-13 QK^T of block 0 (its scores are dead since the X phase), 14-21 P.V of block 1, 22-27 QK^T of block 1.
+      // Block 1's remaining exponentials are spread over slots 0..17, chunk kq complete before its first P.V MFMA (slot 14 + 2 kq) and all
+      // of them before slot 22 overwrites the scores; the six K(t+1) fragment reads go out behind the first MFMA.  The issue order is
+      // pinned (one scheduling region per slot).  Every accumulator sees the same products in the same order as in flash_attn_kernel.
       tsd_jitter();
-      if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
+      if constexpr ((VAR & 2) || FLIP) __builtin_amdgcn_s_setprio(1);
       h8 kf[KSTEPS][2];
-      if constexpr ((VAR & 16) && MORE) k_frags(nx1, kf);
+      f16v z;
 #pragma unroll
-      for (int kq = 0; kq < 4; kq++) {
+      for (int r = 0; r < 16; r++) z[r] = 0.f;
+      constexpr int EXP_SLOTS = 18;
 #pragma unroll
-        for (int qb = 0; qb < QB; qb++)
-#pragma unroll
-          for (int d = 0; d < DBLK; d++) {
-            if constexpr (VAR & 8) asm volatile("" ::"v"(vf[kq][d]), "v"(pf[qb][kq]));
-            else o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kq][d], pf[qb][kq], o[qb][d], 0, 0, 0);
-          }
-        if constexpr (!(VAR & 16)) {
-          if (kq == 1) {  // K(t+1) fragments: six reads in the shadow of the second half of P.V
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MORE) k_frags(nx1, kf);
-            __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 28; i++) {
+        const int qb = i < 14 ? 0 : 1, j = i < 14 ? i : i - 14;
+        if (j < 8) {
+          const int kq = j >> 1, d = j & 1;
+          if constexpr (VAR & 8) asm volatile("" ::"v"(vf[kq][d]), "v"(pf[qb][kq]));
+          else o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kq][d], pf[qb][kq], o[qb][d], 0, 0, 0);
+        } else if constexpr (MORE) {
+          const int ks = (j - 8) >> 1, kb = (j - 8) & 1;
+          if constexpr (VAR & 8) {
+            asm volatile("" ::"v"(kf[ks][kb]), "v"(qf[qb][ks]));
+            if (ks == 0) s[qb][kb] = z;
+          } else {
+            s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][kb], qf[qb][ks], ks == 0 ? z : s[qb][kb], 0, 0, 0);
           }
         }
+        // A wave whose next instruction is an MFMA waiting for the matrix pipe keeps the SIMD's VALU issue to itself: its partner's exponentials
+        // and converts then run AFTER the MFMAs, not under them (scripts/micro/valu_port.hip: 28 MFMAs next to 64 exp + 32 cvt take 1410-1610
+        // clocks, the sum).  Dropping to priority 0 for one instruction behind every MFMA hands the partner the issue slots of the ~28 clocks
+        // the pipe is busy anyway: 1190 clocks for both, whichever wave is older (the flip itself costs the MFMA chain ~10 clocks each).
+        if constexpr (FLIP) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_s_setprio(1); }
+        if constexpr (MORE) {
+          if (i == 0) k_frags(nx1, kf);
+        }
+#pragma unroll
+        for (int pr = XP; pr < 16; pr++)
+          if (((pr - XP) * EXP_SLOTS) / (16 - XP) == i) p_pair(1, pr);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (MORE) qk(kf);
-      if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
+      if constexpr ((VAR & 2) || FLIP) __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       TS8(ts_m, ts0);
@@ -477,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
 template <int D, int VAR>
 static int launch_fa8(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq) {
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1), DBLK = (D + 31) / 32;
-  constexpr int LDS = 3 * (64 * KPITCH * 16 + DBLK * 32 * 128) + 16;  // + the early-abort flag word
+  constexpr int LDS = 3 * (64 * KPITCH * 16 + DBLK * 32 * 128 + 16) + 16;  // three slots (K tile, V^T tile, K pad chunk) + the early-abort flag word
   auto fn = flash_attn8_kernel<D, VAR>;
   static std::atomic<unsigned long long> attr{0};  // one bit per device
   if (!((attr.load(std::memory_order_relaxed) >> (ctx->device & 63)) & 1)) {
@@ -493,16 +530,15 @@ int launch_flash_attention8(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq, 
   if (d != 40) TSD_FAIL(TSD_E_SHAPE, "8-wave flash attention: head dim %d unsupported", d);
   switch (variant) {
 #ifdef TSD_ATTN8_VARIANTS  // timing / A-B builds only
-    case 1: return launch_fa8<40, 1>(ctx, k, B, H, Sq);
-    case 2: return launch_fa8<40, 2>(ctx, k, B, H, Sq);
-    case 3: return launch_fa8<40, 3>(ctx, k, B, H, Sq);
-    case 4: return launch_fa8<40, 4>(ctx, k, B, H, Sq);
-    case 8: return launch_fa8<40, 8>(ctx, k, B, H, Sq);
-    case 12: return launch_fa8<40, 12>(ctx, k, B, H, Sq);
-    case 16: return launch_fa8<40, 16>(ctx, k, B, H, Sq);
-    case 17: return launch_fa8<40, 17>(ctx, k, B, H, Sq);
+    case 128: return launch_fa8<40, 128>(ctx, k, B, H, Sq);
+    case 160: return launch_fa8<40, 160>(ctx, k, B, H, Sq);
+    case 192: return launch_fa8<40, 192>(ctx, k, B, H, Sq);
+    case 256: return launch_fa8<40, 256>(ctx, k, B, H, Sq);
+    case 384: return launch_fa8<40, 384>(ctx, k, B, H, Sq);
+    case 416: return launch_fa8<40, 416>(ctx, k, B, H, Sq);
+    case 448: return launch_fa8<40, 448>(ctx, k, B, H, Sq);
 #endif
-    default: return launch_fa8<40, 0>(ctx, k, B, H, Sq);
+    default: return launch_fa8<40, TSD_ATTN8_DEFAULT_VAR>(ctx, k, B, H, Sq);
   }
 }
 

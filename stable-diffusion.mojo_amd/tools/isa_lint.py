@@ -29,10 +29,19 @@ Checks, per kernel, on the control-flow graph rebuilt from the labels and branch
   R5  (with --lib) the vector-memory / wait instruction stream of every kernel in the shipped libtsd.so, disassembled from its
       embedded code objects, equals the listing's: the listing IS what ships.
 
-Usage:  isa_lint.py [--build-dir DIR] [--contract FILE | --no-contract] [--lib [libtsd.so]] [--update] [--only FILE ...] [-q]
-Exit status 0 = clean, 1 = violations (printed one per line).
+The table carries the compiler it was blessed with (`_meta.hipcc`) and the sha256 of the blessed library's gfx950 code objects
+(`_meta.code_sha256`).  R4 / R5 compare figures that belong to ONE compiler: under another hipcc (a ROCm point release, an EXTRA= flag) or
+without the llvm tools they are reported as warnings, R0-R3 - the safety rules - stay fatal everywhere.
+
+Re-blessing (`--update`) is not a formality: it REFUSES to write unless `--record FILE` (default profiles/bless_record.json) is the evidence
+of a GPU run on exactly the library being blessed - `code_sha256` equal to this library's, >= 1000 identical denoise loops on the shipped
+build and >= 300 on the -DTSD_JITTER build that reproduce the shipped bits (scripts/bless_evidence.sh writes it on the GPU box).
+
+Usage:  isa_lint.py [--build-dir DIR] [--contract FILE | --no-contract] [--lib [libtsd.so]] [--update [--record FILE]] [--only FILE ...] [-q]
+Exit status 0 = clean, 1 = violations (printed one per line), 2 = --update refused.
 """
 import argparse
+import hashlib
 import json
 import os
 import re
@@ -46,6 +55,9 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 DEFAULT_BUILD = os.path.join(CSRC, "build")
 DEFAULT_CONTRACT = os.path.join(CSRC, "isa_contract.json")
 DEFAULT_LIB = os.path.join(os.path.dirname(HERE), "lib", "libtsd.so")
+DEFAULT_RECORD = os.path.join(os.path.dirname(os.path.dirname(HERE)), "profiles", "bless_record.json")
+MIN_RACE_LOOPS, MIN_JITTER_LOOPS = 1000, 300
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LLVM_BIN = os.environ.get("TSD_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 VMEM_RE = re.compile(r"^(buffer|tbuffer|global|flat|scratch|image)_(load|store|atomic|gather|sample)")
@@ -465,8 +477,57 @@ def streams_of_library(lib_path, workdir):
     return streams
 
 
-def run(build_dir=DEFAULT_BUILD, contract=DEFAULT_CONTRACT, lib=None, update=False, only=None, quiet=False, out=sys.stdout):
-    """Returns the list of violations (empty = clean)."""
+def llvm_tools_present():
+    return all(os.path.exists(os.path.join(LLVM_BIN, t)) for t in ("llvm-objcopy", "llvm-objdump"))
+
+
+def code_sha256(lib_path):
+    """sha256 over the gfx950 code objects embedded in the library, in bundle order: what the GPU executes (host code does not count)."""
+    import tempfile
+    h = hashlib.sha256()
+    with tempfile.TemporaryDirectory() as td:
+        for co in code_objects(lib_path, td):
+            with open(co, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def hipcc_version():
+    """One line that names the compiler (HIP version + clang version); '' when hipcc cannot be run."""
+    try:
+        txt = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return ""
+    keep = [ln.strip() for ln in txt.splitlines() if ln.startswith("HIP version") or "clang version" in ln]
+    return " | ".join(keep)
+
+
+def check_record(record, lib):
+    """-> list of reasons why `record` does not license blessing `lib` (empty = it does)."""
+    if not record or not os.path.exists(record):
+        return ["no evidence record %s (scripts/bless_evidence.sh writes it on the GPU box)" % record]
+    try:
+        rec = json.load(open(record))
+    except ValueError as e:
+        return ["evidence record %s is not JSON: %s" % (record, e)]
+    why = []
+    have = code_sha256(lib)
+    if rec.get("code_sha256") != have:
+        why.append("the record is for another build (code objects %s..., this library %s...)" % (str(rec.get("code_sha256"))[:12], have[:12]))
+    if int(rec.get("race_loops", 0)) < MIN_RACE_LOOPS or int(rec.get("race_distinct", 0)) != 1:
+        why.append("needs >= %d identical denoise loops on the shipped build with ONE result (record: %s loops, %s distinct)"
+                   % (MIN_RACE_LOOPS, rec.get("race_loops"), rec.get("race_distinct")))
+    if int(rec.get("jitter_loops", 0)) < MIN_JITTER_LOOPS or not rec.get("jitter_matches_shipped"):
+        why.append("needs >= %d loops of the -DTSD_JITTER build reproducing the shipped bits (record: %s loops, matches: %s)"
+                   % (MIN_JITTER_LOOPS, rec.get("jitter_loops"), rec.get("jitter_matches_shipped")))
+    return why
+
+
+def run(build_dir=DEFAULT_BUILD, contract=DEFAULT_CONTRACT, lib=None, update=False, only=None, quiet=False, out=sys.stdout, record=None,
+        warnings=None):
+    """Returns the list of violations (empty = clean).  R4 / R5 findings under a compiler other than the blessed one (or without the llvm
+    tools) go to `warnings` (a list, optional) instead: they compare one compiler's figures."""
+    warn = warnings if warnings is not None else []
     files = sorted(f for f in os.listdir(build_dir) if f.endswith("-hip-amdgcn-amd-amdhsa-gfx950.s")) if os.path.isdir(build_dir) else []
     if only:
         files = [f for f in files if f in only or f.split("-hip-")[0] in only]
@@ -484,28 +545,51 @@ def run(build_dir=DEFAULT_BUILD, contract=DEFAULT_CONTRACT, lib=None, update=Fal
             ft[name] = rec
             listing_streams[name] = stream_of_listing(blocks)
         table[fn.split("-hip-")[0]] = ft
-    if lib:
+    r45 = []   # R4 / R5 findings: fatal only under the blessed compiler
+    if lib and not llvm_tools_present():
+        warn.append("R5 skipped: llvm-objcopy / llvm-objdump not in %s (TSD_LLVM_BIN)" % LLVM_BIN)
+        lib_checked = None
+    else:
+        lib_checked = lib
+    if lib_checked:
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             shipped = streams_of_library(lib, td)
         if not shipped:
-            viol.append("R5 no gfx950 code object found in %s" % lib)
+            r45.append("R5 no gfx950 code object found in %s" % lib)
         for name, st in listing_streams.items():
             if name not in shipped:
                 # device functions that were inlined everywhere have a listing body but no symbol in the object: kernels must be there
                 if any(name in t and "regs" in t[name] for t in table.values()):
-                    viol.append("R5 %s: kernel of the listing is not in %s" % (name, os.path.basename(lib)))
+                    r45.append("R5 %s: kernel of the listing is not in %s" % (name, os.path.basename(lib)))
                 continue
             if shipped[name] != st:
-                viol.append("R5 %s: the shipped object's vector-memory / wait stream (%d instructions) differs from the listing's (%d): "
+                r45.append("R5 %s: the shipped object's vector-memory / wait stream (%d instructions) differs from the listing's (%d): "
                             "the library was not built from these listings" % (name, len(shipped[name]), len(st)))
+    blessed_hipcc = None
     if update:
+        if viol:
+            print("isa_lint: --update refused: the build violates R0-R3", file=out)
+            for v in viol:
+                print("  " + v, file=out)
+            return viol + ["update refused"]
+        the_lib = lib or DEFAULT_LIB
+        why = check_record(record or DEFAULT_RECORD, the_lib) if llvm_tools_present() else ["llvm tools missing: cannot hash the library's code objects"]
+        if why:
+            print("isa_lint: --update REFUSED - a re-bless goes with the GPU evidence for exactly this library:", file=out)
+            for w in why:
+                print("  " + w, file=out)
+            return ["update refused: " + w for w in why]
         if only:
             old = json.load(open(contract), object_pairs_hook=OrderedDict) if os.path.exists(contract) else OrderedDict()
             old.update(table)
             table = old
+        table.pop("_meta", None)
+        full = OrderedDict([("_meta", OrderedDict([("hipcc", hipcc_version()), ("code_sha256", code_sha256(the_lib)),
+                                                    ("record", os.path.relpath(record or DEFAULT_RECORD, os.path.dirname(os.path.dirname(HERE))))]))])
+        full.update(table)
         with open(contract, "w") as f:
-            json.dump(table, f, indent=1)
+            json.dump(full, f, indent=1)
             f.write("\n")
         if not quiet:
             print("isa_lint: wrote %s (%d kernels)" % (contract, sum(len(t) for t in table.values())), file=out)
@@ -514,22 +598,34 @@ def run(build_dir=DEFAULT_BUILD, contract=DEFAULT_CONTRACT, lib=None, update=Fal
             viol.append("R4 no committed table %s (isa_lint.py --update writes it)" % contract)
         else:
             want = json.load(open(contract), object_pairs_hook=OrderedDict)
+            blessed_hipcc = (want.pop("_meta", None) or {}).get("hipcc")
             for fkey, ft in table.items():
                 wt = want.get(fkey)
                 if wt is None:
-                    viol.append("R4 %s: file not in the committed table" % fkey)
+                    r45.append("R4 %s: file not in the committed table" % fkey)
                     continue
                 for name, rec in ft.items():
                     if name not in wt:
-                        viol.append("R4 %s: %s: kernel not in the committed table" % (fkey, name))
+                        r45.append("R4 %s: %s: kernel not in the committed table" % (fkey, name))
                         continue
                     for key in set(rec) | set(wt[name]):
                         if rec.get(key) != wt[name].get(key):
-                            viol.append("R4 %s: %s: %s drifted from the committed table\n      now : %s\n      was : %s"
+                            r45.append("R4 %s: %s: %s drifted from the committed table\n      now : %s\n      was : %s"
                                         % (fkey, name, key, json.dumps(rec.get(key)), json.dumps(wt[name].get(key))))
                 for name in wt:
                     if name not in ft:
-                        viol.append("R4 %s: %s: kernel of the committed table is gone" % (fkey, name))
+                        r45.append("R4 %s: %s: kernel of the committed table is gone" % (fkey, name))
+    # R4 / R5 are statements about ONE compiler's output: under another hipcc they inform, they do not fail the build
+    if r45:
+        now = hipcc_version()
+        if blessed_hipcc and now and now != blessed_hipcc:
+            warn.append("compiler differs from the blessed one (%s; table: %s): %d R4 / R5 finding(s) reported as warnings" % (now, blessed_hipcc, len(r45)))
+            warn += r45
+        else:
+            viol += r45
+    if not quiet:
+        for w in warn:
+            print("  warning: " + w, file=out)
     if not quiet:
         nk = sum(len(t) for t in table.values())
         ns = sum(int(re.search(r"counted=(\d+)", r["waits"]).group(1)) for t in table.values() for r in t.values())
@@ -547,11 +643,12 @@ def main():
     ap.add_argument("--no-contract", action="store_true", help="rules R0-R3 only (a build that is not the shipped one)")
     ap.add_argument("--lib", nargs="?", const=DEFAULT_LIB, default=None)
     ap.add_argument("--update", action="store_true")
+    ap.add_argument("--record", default=None, help="evidence record of the GPU run that licenses --update (default profiles/bless_record.json)")
     ap.add_argument("--only", nargs="*")
     ap.add_argument("-q", "--quiet", action="store_true")
     a = ap.parse_args()
-    v = run(a.build_dir, None if a.no_contract else a.contract, a.lib, a.update, a.only, a.quiet)
-    sys.exit(1 if v else 0)
+    v = run(a.build_dir, None if a.no_contract else a.contract, a.lib, a.update, a.only, a.quiet, record=a.record)
+    sys.exit((2 if any(x.startswith("update refused") for x in v) else 1) if v else 0)
 
 
 if __name__ == "__main__":

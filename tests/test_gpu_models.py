@@ -588,17 +588,19 @@ def test_denoise_loop_is_bitwise_repeatable_200_runs(gpu_ctx, tsd_mod, diffusion
 
 def test_jitter_build_reproduces_the_shipped_bits():
     """The hazard-hunting build (`make jitter`: -DTSD_JITTER puts a random wave-level delay at every tile step, barrier, split-K
-    hand-off and epilogue of the GEMM, flash-attention and fused attention-block kernels) runs the headline denoise loop 300
-    times (TSD_JITTER_LOOPS; 600 = three times the shipped build's 200-run test took 6.4 of the suite's 10 minutes - scripts/jitter_check.sh
-    and the round's evidence runs use the longer loops) and must give the ONE result the shipped library gives.  A kernel whose waves are correctly ordered keeps its bits whatever
+    hand-off and epilogue of the GEMM, flash-attention and fused attention-block kernels) runs the headline denoise loop 600
+    times (TSD_JITTER_LOOPS; three times the shipped build's 200-run test: ~6 of the suite's ~13 minutes; scripts/jitter_check.sh runs the
+    whole GPU suite on it) and must give the ONE result the shipped library gives.  A kernel whose waves are correctly ordered keeps its bits whatever
     the delays; a hazard that the shipped schedule hides most of the time (round 4: 1 run in 100) shows up within a few loops.
     Each library runs in a process of its own (TSD_LIB picks it)."""
+    import ast
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     jit = os.path.join(root, "stable-diffusion.mojo_amd", "lib", "libtsd_jitter.so")
-    assert os.path.exists(jit), f"{jit} not built - __graft_entry__.build() runs `make all jitter`"
+    if not os.path.exists(jit):
+        pytest.skip(f"{jit} not built (`make -C stable-diffusion.mojo_amd/csrc jitter`; __graft_entry__.build() builds it)")
 
     def run(n, lib=None):
         env = dict(os.environ, N=str(n))
@@ -610,11 +612,11 @@ def test_jitter_build_reproduces_the_shipped_bits():
         assert out.returncode == 0, out.stdout[-2000:]
         m = re.search(r"(\d+) distinct (\{.*\})", out.stdout)
         assert m, out.stdout[-2000:]
-        return eval(m.group(2))  # {hash: count}
+        return ast.literal_eval(m.group(2))  # {hash: count}
 
     ref = run(2)
     assert len(ref) == 1, ref
-    got = run(int(os.environ.get("TSD_JITTER_LOOPS", "300")), jit)
+    got = run(int(os.environ.get("TSD_JITTER_LOOPS", "600")), jit)
     assert got.keys() == ref.keys(), f"shipped build {ref}, jitter build {got}"
 
 

@@ -35,8 +35,11 @@ def test_shipped_build_keeps_the_counted_wait_contract():
 def test_contract_table_covers_every_counted_wait_of_the_tile_pipelines():
     import json
     table = json.load(open(isa_lint.DEFAULT_CONTRACT))
+    meta = table.pop("_meta")
+    assert len(meta["code_sha256"]) == 64 and "clang version" in meta["hipcc"] and os.path.exists(os.path.join(ROOT, meta["record"])), meta
     counted = {k: sum(int(r["waits"].split("counted=")[1].split()[0]) for r in t.values()) for k, t in table.items()}
     assert counted["kernels_gemm"] >= 200 and counted["kernels_chain"] >= 100, counted
+    assert counted["kernels_attn8"] >= 4, counted   # the 8-wave flash attention: two alternatives per pass (waves with one / two DMA pieces per tile)
     assert counted["kernels_attn"] == 0 and counted["kernels_norm"] == 0 and counted["kernels_elementwise"] == 0, counted
     # no MFMA kernel may touch scratch (3848 scratch accesses were lost once without anybody noticing)
     spills = {n: r["regs"] for t in table.values() for n, r in t.items() if "regs" in r and "scratch=0" not in r["regs"]}
@@ -61,8 +64,62 @@ def test_lint_fails_on_the_round4_wait(tmp_path):
     # and the shipped flavour of the same file is clean under the same rules
     out2 = tmp_path / "build2"
     out2.mkdir()
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "ARCH=gfx950"], stdout=subprocess.DEVNULL)  # (a no-op when current; run in isolation it builds)
     shutil.copy(os.path.join(CSRC, "build", "kernels_chain-hip-amdgcn-amd-amdhsa-gfx950.s"), str(out2))
     assert isa_lint.run(build_dir=str(out2), contract=None, quiet=True) == []
+
+
+# ---- re-blessing the table needs the GPU evidence for exactly this library ------------------------------------------------------
+def _record(tmp_path, **over):
+    import json
+    rec = {"code_sha256": isa_lint.code_sha256(isa_lint.DEFAULT_LIB), "race_loops": 1000, "race_distinct": 1, "jitter_loops": 300,
+           "jitter_matches_shipped": True}
+    rec.update(over)
+    p = tmp_path / "record.json"
+    p.write_text(json.dumps(rec))
+    return str(p)
+
+
+@needs_hipcc
+def test_rebless_is_refused_without_the_evidence_record(tmp_path):
+    """`isa_lint.py --update` used to rewrite 1089 lines of isa_contract.json on request; the rule that a re-bless goes with the jitter run and
+    >= 1000 determinism loops was prose.  Now: no record, a record of another build, too few loops or more than one result -> refused, the
+    table is not touched; the command line exits with status 2."""
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "ARCH=gfx950"], stdout=subprocess.DEVNULL)
+    table = tmp_path / "contract.json"
+    for rec in (str(tmp_path / "missing.json"), _record(tmp_path, code_sha256="0" * 64), _record(tmp_path, race_loops=200),
+                _record(tmp_path, race_distinct=2), _record(tmp_path, jitter_loops=100), _record(tmp_path, jitter_matches_shipped=False)):
+        v = isa_lint.run(lib=isa_lint.DEFAULT_LIB, contract=str(table), update=True, record=rec, quiet=True, out=open(os.devnull, "w"))
+        assert v and all(x.startswith("update refused") for x in v), v
+        assert not table.exists()
+    r = subprocess.run([sys.executable, os.path.join(PKG, "tools", "isa_lint.py"), "--lib", "--contract", str(table), "--update", "--record",
+                        str(tmp_path / "missing.json")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 2 and "REFUSED" in r.stdout, (r.returncode, r.stdout[-500:])
+    assert not table.exists()
+
+
+@needs_hipcc
+def test_rebless_with_the_record_names_compiler_and_code_objects_and_other_compilers_only_warn(tmp_path):
+    """With the record of this very library the table is written and carries `_meta` (hipcc version, sha256 of the code objects, the record).
+    A drifted figure then fails R4 under the same compiler - and is a WARNING under another one (a ROCm point release must not turn a
+    correct library into a failed build; R0-R3 stay fatal)."""
+    import json
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "ARCH=gfx950"], stdout=subprocess.DEVNULL)
+    table = tmp_path / "contract.json"
+    assert isa_lint.run(lib=isa_lint.DEFAULT_LIB, contract=str(table), update=True, record=_record(tmp_path), quiet=True) == []
+    t = json.load(open(table))
+    assert t["_meta"]["code_sha256"] == isa_lint.code_sha256(isa_lint.DEFAULT_LIB) and "clang version" in t["_meta"]["hipcc"], t["_meta"]
+    assert isa_lint.run(lib=isa_lint.DEFAULT_LIB, contract=str(table), quiet=True) == []
+    name = next(n for n, r in t["kernels_gemm"].items() if "regs" in r)
+    t["kernels_gemm"][name]["regs"] = "vgpr=1 agpr=0 sgpr_spill=0 vgpr_spill=0 scratch=0"
+    json.dump(t, open(table, "w"))
+    v = isa_lint.run(lib=isa_lint.DEFAULT_LIB, contract=str(table), quiet=True)
+    assert len(v) == 1 and "R4" in v[0] and "regs drifted" in v[0], v
+    t["_meta"]["hipcc"] = "HIP version: 9.9.9 | some other clang version 99"
+    json.dump(t, open(table, "w"))
+    w = []
+    assert isa_lint.run(lib=isa_lint.DEFAULT_LIB, contract=str(table), quiet=True, warnings=w) == []
+    assert any("compiler differs" in x for x in w) and any("regs drifted" in x for x in w), w
 
 
 # ---- hand-written listings -----------------------------------------------------------------------------------------------------
