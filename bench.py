@@ -236,20 +236,25 @@ def peaked_logits_bench(tsd, ctx, B, L, T, lat, cx, noise, n_sched, K, friendly_
 
 # one tile per CU in every run: rows x columns of the problem = 256 tiles of the configuration
 K_LOOP_PROBES = (
-    # (label, conv, B, H, W, N, (K-defining Cin short, long), tile configuration, FM, FN, compute waves per SIMD, tile rows, tile columns)
-    ("conv3x3 C->320 @64x64, 256x160 staggered tile + loader waves (cfg 51: the six 64x64-level convs)", 1, 8, 64, 64, 320, (320, 640), 51, 4, 5, 2, 256, 160),
-    ("conv3x3 C->640 @32x32, 128x160 tile, 3-slot ring (cfg 5: the 32x32-level convs)", 1, 8, 32, 32, 640, (640, 1280), 5, 4, 5, 1, 128, 160),
-    ("dense 8192x640xK, 128x160 staggered tile + loader waves (cfg 54: 15 launches per step at K = 640)", 0, 8, 32, 32, 640, (640, 2560), 54, 2, 5, 2, 128, 160),
-    ("dense 2048x1280xK, 64x160 tile + loader waves (cfg 47: 15 launches per step at K = 1280)", 0, 8, 16, 16, 1280, (1280, 5120), 47, 2, 5, 1, 64, 160),
+    # (label, conv, B, H, W, N, Cin of the in-step launch (K lengths = 1x..4x), tile configuration, FM, FN, compute waves per SIMD, tile rows, tile columns)
+    ("conv3x3 C->320 @64x64, 256x160 staggered tile + loader waves (cfg 51: the six 64x64-level convs)", 1, 8, 64, 64, 320, 320, 51, 4, 5, 2, 256, 160),
+    ("conv3x3 C->640 @32x32, 128x160 tile, 3-slot ring (cfg 5: the 32x32-level convs)", 1, 8, 32, 32, 640, 640, 5, 4, 5, 1, 128, 160),
+    ("dense 8192x640xK, 128x160 staggered tile + loader waves (cfg 54: 15 launches per step at K = 640)", 0, 8, 32, 32, 640, 640, 54, 2, 5, 2, 128, 160),
+    ("dense 2048x1280xK, 64x160 tile + loader waves (cfg 47: 15 launches per step at K = 1280)", 0, 8, 16, 16, 1280, 1280, 47, 2, 5, 1, 64, 160),
 )
+K_LOOP_LENGTHS, K_LOOP_REPEATS, K_LOOP_ITERS, K_LOOP_FIXED_TOL_US = (1, 2, 3, 4), 3, 20, 2.0
 
 
-def k_loop_model(tsd, dev_index):
-    """What a K tile costs, measured live: the same one-tile-per-CU launch at two K lengths (real epilogue: bias + residual) gives
-    time = fixed + slope x K-tiles.  slope -> the chip-wide rate INSIDE the K loop (clock-free: flop per K tile / slope) against the
-    fp16 MFMA peak, next to the MFMA clocks the tile needs (16 per v_mfma_f32_16x16x32_f16, per SIMD) - the rest of a K tile's clocks
-    are its LDS phases (fragment reads, the DMA's LDS writes, barriers; DESIGN.md 4.1 "what a K tile costs").  fixed -> prologue, ring
-    fill, drain and epilogue per launch.  Whether 0.40 of the peak is reachable at batch 8 follows from these two numbers per tile."""
+def k_loop_model(tsd, dev_index, in_step=None, probes=K_LOOP_PROBES):
+    """What a K tile and a launch cost, as a MEASUREMENT: the same one-tile-per-CU launch (real epilogue: bias + residual) at FOUR K
+    lengths, three interleaved repeats, a least-squares line per repeat: time = fixed + slope x K-tiles.  Reported: mean slope and
+    intercept, their spread over the repeats (half the range) and the residual of the fit.  A configuration whose intercept moves by
+    more than +-2 us between repeats is reported as `unstable` with its raw times and NO derived figure (round 5 printed a two-point
+    intercept that swung 9x between boxes).  slope -> the chip-wide rate INSIDE the K loop against the fp16 MFMA peak, next to the MFMA
+    clocks the tile needs (16 per v_mfma_f32_16x16x32_f16, per SIMD); fixed -> prologue, ring fill, drain and epilogue of a REPEATED,
+    WARM launch.  `in_step` = the per-launch records of the profiled step (class, M, N, K, batch, ms): the same shape's duration inside
+    the step, and the difference to the warm model at that K (`cold_us_per_launch`: operands that are not in the L2 when the launch
+    starts - what the model does not contain)."""
     import ctypes as C
     from tsd._lib import lib
     old = os.environ.get("TSD_BENCH_EPI")
@@ -262,31 +267,55 @@ def k_loop_model(tsd, dev_index):
         else:
             os.environ["TSD_BENCH_EPI"] = old
     out = []
-    for label, conv, B_, H, W, N, cins, cfg, FM, FN, wps, BM, BN in K_LOOP_PROBES:
-        us, kts = [], []
-        for cin in cins:
-            ms = C.c_float()
-            r = lib().tsd_debug_gemm_bench(c2.h, conv, B_, H, W, cin, N, 1, 0, cfg, 30, C.byref(ms))
-            if r != 0:
-                us = None
+    for label, conv, B_, H, W, N, cin0, cfg, FM, FN, wps, BM, BN in probes:
+        cins = [cin0 * m for m in K_LOOP_LENGTHS]
+        kts = [(9 * c if conv else c) // 64 for c in cins]
+        us = np.zeros((K_LOOP_REPEATS, len(cins)))
+        ok = True
+        for rep in range(K_LOOP_REPEATS):
+            for i, cin in enumerate(cins):
+                ms = C.c_float()
+                if lib().tsd_debug_gemm_bench(c2.h, conv, B_, H, W, cin, N, 1, 0, cfg, K_LOOP_ITERS, C.byref(ms)) != 0:
+                    ok = False
+                    break
+                us[rep, i] = ms.value * 1e3
+            if not ok:
                 break
-            us.append(ms.value * 1e3)
-            kts.append((9 * cin if conv else cin) // 64)
-        if not us:
+        if not ok:
             out.append({"tile": label, "error": "tsd_debug_gemm_bench failed"})
             continue
-        slope = (us[1] - us[0]) / (kts[1] - kts[0])
-        fixed = us[0] - slope * kts[0]
+        fits = [np.polyfit(kts, us[rep], 1) for rep in range(K_LOOP_REPEATS)]   # (slope, intercept) per repeat
+        slopes, fixeds = np.array([f[0] for f in fits]), np.array([f[1] for f in fits])
+        slope, fixed = float(slopes.mean()), float(fixeds.mean())
+        slope_spread, fixed_spread = float(np.ptp(slopes) / 2), float(np.ptp(fixeds) / 2)
+        resid = float(np.sqrt(np.mean([(np.polyval(f, kts) - us[rep]) ** 2 for rep, f in enumerate(fits)])))
+        rec = {"tile": label, "cfg": cfg, "k_tiles": kts, "launch_us": [[round(float(u), 2) for u in row] for row in us],
+               "us_per_k_tile": round(slope, 4), "us_per_k_tile_spread": round(slope_spread, 4),
+               "fixed_us_per_launch": round(fixed, 2), "fixed_us_spread": round(fixed_spread, 2), "fit_residual_us_rms": round(resid, 3),
+               "fit": "least squares over %d K lengths, %d repeats of %d launches; spread = half the range over the repeats" % (len(kts), K_LOOP_REPEATS, K_LOOP_ITERS)}
+        if fixed_spread > K_LOOP_FIXED_TOL_US or slope <= 0:
+            rec["unstable"] = True   # no derived figure from an intercept that does not reproduce on this box
+            out.append(rec)
+            continue
         flop_kt = 256.0 * BM * BN * 64 * 2          # all 256 CUs, one K tile each
         loop_tf = flop_kt / (slope * 1e-6) / 1e12
         mfma_clk = wps * 2 * FM * FN * 16
         meas_clk = slope * 1e-6 * 2.4e9             # clocks of the 2.4 GHz the nominal peak assumes
-        out.append({"tile": label, "k_tiles": kts, "launch_us": [round(u, 2) for u in us], "us_per_k_tile": round(slope, 4),
-                    "fixed_us_per_launch": round(fixed, 2), "mfma_clk_per_k_tile": mfma_clk,
-                    "measured_clk_per_k_tile_at_2p4GHz": round(meas_clk, 0), "lds_and_barrier_clk_per_k_tile": round(meas_clk - mfma_clk, 0),
+        rec.update({"mfma_clk_per_k_tile": mfma_clk, "measured_clk_per_k_tile_at_2p4GHz": round(meas_clk, 0),
+                    "lds_and_barrier_clk_per_k_tile": round(meas_clk - mfma_clk, 0),
                     "k_loop_tflops": round(loop_tf, 1), "k_loop_frac_of_peak": round(loop_tf / PEAK_FP16_TFLOPS, 4),
                     "whole_launch_frac_of_peak": {str(kt): round(flop_kt * kt / ((fixed + slope * kt) * 1e-6) / 1e12 / PEAK_FP16_TFLOPS, 4)
                                                    for kt in kts}})
+        if in_step:
+            rows, K0 = B_ * H * W, (9 * cin0 if conv else cin0)
+            hit = [r[5] * 1e3 for r in in_step if r[0] == ("conv3x3" if conv else "gemm") and r[2] == N and r[3] == K0
+                   and (r[1] == rows or r[1] * max(1, r[4]) == rows)]
+            if hit:
+                warm = fixed + slope * kts[0]
+                rec.update({"in_step_launches": len(hit), "in_step_us_per_launch": round(float(np.mean(hit)), 2),
+                            "warm_model_us_at_that_k": round(warm, 2), "cold_us_per_launch": round(float(np.mean(hit)) - warm, 2),
+                            "in_step_note": "in-step times: hipEvent pairs of the profiling pass, roofline.event_overhead_us_per_launch_removed taken off"})
+        out.append(rec)
     lib().tsd_ctx_destroy(c2.h)
     c2.h = None
     return out
@@ -620,7 +649,7 @@ def main():
             roofline["mfma_sustained_probe"] = {"error": str(e)}
         if args.kloop:
             try:
-                roofline["k_loop_model"] = k_loop_model(tsd, dev_index)
+                roofline["k_loop_model"] = k_loop_model(tsd, dev_index, in_step=[(r[0], r[1], r[2], r[3], r[4], max(0.0, r[5] - ev_overhead_ms)) for r in recs])
             except Exception as e:  # a probe must never cost the bench line
                 roofline["k_loop_model"] = {"error": str(e)}
         # ---- VAE decode time (images/s end-to-end = B / (50 * step + decode)) ----
