@@ -58,6 +58,7 @@ struct TsdOptions {
   int gn_composite = 1;    // TSD_GN_COMPOSITE: GroupNorm over a channel concat from the two producers' partial statistics
   int conv_in_im2col = 1;  // TSD_CONV_IN_IM2COL: the 4-channel input convolution as one im2col K tile
   int chain = 1;           // TSD_CHAIN: fused head / tail kernels of the 64x64-level attention blocks
+  int fold_out = 1;        // TSD_FOLD_OUT: op-by-op attention blocks (C = 640 / 1280): GEGLU's second linear + the output 1x1 conv as one GEMM over [h | r]
   // derived weight copies (model.cpp; read when a model's derived buffers are built)
   int conv_w_tm_mib = 2, lin_w_tm = 1, lin_w_tm_kib = 1024;  // TSD_CONV_W_TM, TSD_LIN_W_TM, TSD_LIN_W_TM_KIB
   // flash attention (kernels_attn.hip)
@@ -258,6 +259,10 @@ int launch_chw_f32_to_nhwc_f16(tsd_ctx* ctx, const float* src, int B, int C, int
 int launch_chw_f32_to_im2col3x3_f16(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, half_t* dst, float scale = 1.f);
 int launch_pack_im2col_w(tsd_ctx* ctx, const half_t* w, int O, int Ipad, int C, half_t* dst);
 int launch_pack_tile_major(tsd_ctx* ctx, const half_t* w, int N, int K, half_t* dst);  // [N][K] -> [K/64][N][64]
+// fold of a linear layer into the 1x1 convolution that follows it: wf[n][0..K2) = sum_j wo[n][j] * w2[j][k], wf[n][K2..K2+C) = wo[n][..],
+// bf[n] = sum_j wo[n][j] * b2[j] + bo[n]  (fp32 sums in index order, one rounding to fp16 per folded weight)
+int launch_fold_linear_conv1x1(tsd_ctx* ctx, const half_t* wo, int ldo, const float* bo, const half_t* w2, int ld2, const float* b2, int C, int K2,
+                               half_t* wf, int ldf, float* bf);
 int launch_nhwc_f16_to_chw_f32(tsd_ctx* ctx, const half_t* src, int B, int C, int H, int W, int ld, float* dst);
 int launch_nhwc_f32_to_chw_f32(tsd_ctx* ctx, const float* src, int B, int C, int H, int W, int ld, float* dst);
 int launch_f32_to_f16_rows(tsd_ctx* ctx, const float* src, int64_t rows, int cols, half_t* dst, int ld_dst,

@@ -315,8 +315,16 @@ int g_unet_attn(tsd_ctx* ctx, const Act& x, const AttnW& w, const half_t* ctx16,
   } else {
     TSD_TRY(g_linear(ctx, a, M, w.geglu1.w, w.geglu1.Kpad, 8 * C, C, w.geglu1.b, nullptr, 0, EPI_GEGLU, gg, 4 * C, nullptr, S, w.geglu1.w_tm));
   }
-  half_t* tok4 = tok2;  // tok2 is dead after tok3
   CatSrc ag; ag.p0 = gg; ag.ld0 = 4 * C; ag.C0 = 4 * C;
+  if (w.fold_w && ctx->opt.fold_out) {
+    // GEGLU's second linear + residual (:143) and the output 1x1 conv + long residual (:146) are linear in [h | tok3]: ONE GEMM over the
+    // channel concat with the weights folded at model_check_ready (AttnW::fold_w) - a launch and an M x C round trip fewer per block
+    ag.p1 = tok3; ag.ld1 = C; ag.C1 = C;
+    TSD_TRY(g_linear(ctx, ag, M, w.fold_w, 5 * C, C, 5 * C, w.fold_b, x.p, x.ld, 0, out.p, out.ld, &out, S, w.fold_w_tm));
+    ctx->arena.release(mark);
+    return TSD_OK;
+  }
+  half_t* tok4 = tok2;  // tok2 is dead after tok3
   TSD_TRY(g_linear(ctx, ag, M, w.geglu2.w, w.geglu2.Kpad, C, 4 * C, w.geglu2.b, tok3, C, 0, tok4, C, nullptr, S, w.geglu2.w_tm));
   // ---- output 1x1 conv + long residual (:146) ----
   a.p0 = tok4;

@@ -110,6 +110,34 @@ int launch_pack_tile_major(tsd_ctx* ctx, const half_t* w, int N, int K, half_t* 
   return TSD_OK;
 }
 
+// Linear layer folded into the 1x1 convolution behind it (model_check_ready; the attention blocks that run op by op): one thread per folded
+// weight, fp32 sum over the C inner channels in index order (deterministic), one rounding to fp16.  8.4 G multiply-adds at C = 1280: a few ms, once.
+__global__ __launch_bounds__(256) void k_fold_linear_conv1x1(const half_t* __restrict__ wo, int ldo, const float* __restrict__ bo, const half_t* __restrict__ w2, int ld2,
+                                                             const float* __restrict__ b2, int C, int K2, half_t* __restrict__ wf, int ldf, float* __restrict__ bf) {
+  const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  const half_t* won = wo + (int64_t)n * ldo;
+  if (k < K2) {
+    float acc = 0.f;
+    for (int j = 0; j < C; j++) acc += (float)won[j] * (float)w2[(int64_t)j * ld2 + k];
+    wf[(int64_t)n * ldf + k] = (half_t)acc;
+  } else if (k < K2 + C) {
+    wf[(int64_t)n * ldf + k] = won[k - K2];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float acc = 0.f;
+    if (b2) for (int j = 0; j < C; j++) acc += (float)won[j] * b2[j];
+    bf[n] = acc + (bo ? bo[n] : 0.f);
+  }
+}
+int launch_fold_linear_conv1x1(tsd_ctx* ctx, const half_t* wo, int ldo, const float* bo, const half_t* w2, int ld2, const float* b2, int C, int K2,
+                               half_t* wf, int ldf, float* bf) {
+  if (C <= 0 || K2 <= 0 || ldo < C || ld2 < K2 || ldf < K2 + C) TSD_FAIL(TSD_E_SHAPE, "fold: C=%d K2=%d pitches %d / %d / %d", C, K2, ldo, ld2, ldf);
+  if (!ctx->launch()) return TSD_OK;
+  hipLaunchKernelGGL(k_fold_linear_conv1x1, dim3((K2 + C + 255) / 256, C), dim3(256), 0, ctx->stream, wo, ldo, bo, w2, ld2, b2, C, K2, wf, ldf, bf);
+  HIP_TRY(hipGetLastError());
+  return TSD_OK;
+}
+
 // ---- non-finite accounting at the device -> caller exits ------------------------------------------------------------------
 // The reference computes in fp32 (helpers/utils.mojo:12-15) and cannot overflow at the path's magnitudes; this path stores
 // activations as fp16 (|x| <= 65504).  An overflow turns into inf / NaN that the following norms and GEMMs spread, so it reaches

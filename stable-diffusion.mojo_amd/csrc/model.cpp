@@ -21,7 +21,7 @@ bool attn_head_weights_ok(const AttnW& w) {
 // parameters changed: derived buffers are stale until the next model_check_ready()
 static void model_invalidate_derived(tsd_model* m) {
   m->ready = false;
-  for (auto& a : m->unet.attn) { a.tail_stream = nullptr; a.head_stream = nullptr; }
+  for (auto& a : m->unet.attn) { a.tail_stream = nullptr; a.head_stream = nullptr; a.fold_w = nullptr; a.fold_w_tm = nullptr; a.fold_b = nullptr; }
   m->unet.conv_in_im2col = nullptr;
   m->vae.conv_in_im2col = nullptr;
   for (auto& r : m->unet.res) { r.conv1.w_tm = nullptr; r.conv2.w_tm = nullptr; }
@@ -232,9 +232,19 @@ static int model_build_derived(tsd_model* m) {
     kv = &m->unet.kproj_all;
     tm_b += (((size_t)2 * kv->N * kv->Kpad * 2) + 255) & ~size_t(255);
   }
-  if (el.empty() && !cin_ok && tm.empty() && tml.empty() && !kv) return TSD_OK;
+  // GEGLU's second linear folded into the output 1x1 convolution (AttnW::fold_w): blocks that do not run the fused tail kernel
+  std::vector<AttnW*> fold;
+  size_t fold_b = 0;
+  if (ctx->opt.fold_out)
+    for (auto& a : m->unet.attn)
+      if (a.C && !attn_tail_weights_ok(a) && a.geglu2.w && a.conv_out.w && a.conv_out.k == 1 && a.conv_out.Ipad == a.C && a.conv_out.Opad == a.C &&
+          a.geglu2.N == a.C && a.geglu2.Kpad == 4 * a.C && a.geglu2.K == 4 * a.C && a.C % 64 == 0) {
+        fold.push_back(&a);
+        fold_b += 2 * ((((size_t)a.C * 5 * a.C * 2) + 255) & ~size_t(255)) + ((((size_t)a.C * 4) + 255) & ~size_t(255));
+      }
+  if (el.empty() && !cin_ok && tm.empty() && tml.empty() && !kv && fold.empty()) return TSD_OK;
   const size_t tail_b = (attn_tail_stream_bytes() + 255) & ~size_t(255), head_b = (attn_head_stream_bytes() + 255) & ~size_t(255);
-  const size_t each = tail_b + head_b, need = each * el.size() + cin_b + tm_b;
+  const size_t each = tail_b + head_b, need = each * el.size() + cin_b + tm_b + fold_b;
   HIP_TRY(hipSetDevice(ctx->device));
   if (m->derived_bytes < need) {
     if (m->derived) HIP_TRY(hipFree(m->derived));
@@ -287,6 +297,18 @@ static int model_build_derived(tsd_model* m) {
       r = launch_pack_tile_major(ctx, l->w, l->N, l->Kpad, dst);
       if (r == TSD_OK) l->w_tm = dst;
       off += (((size_t)l->N * l->Kpad * 2) + 255) & ~size_t(255);
+    }
+    for (size_t i = 0; i < fold.size() && r == TSD_OK; i++) {
+      AttnW* a = fold[i];
+      const int C = a->C;
+      const size_t wb = (((size_t)C * 5 * C * 2) + 255) & ~size_t(255);
+      half_t* wf = (half_t*)(m->derived + off);
+      half_t* wf_tm = (half_t*)(m->derived + off + wb);
+      float* bf = (float*)(m->derived + off + 2 * wb);
+      r = launch_fold_linear_conv1x1(ctx, a->conv_out.w, a->conv_out.Ipad, a->conv_out.b, a->geglu2.w, a->geglu2.Kpad, a->geglu2.b, C, 4 * C, wf, 5 * C, bf);
+      if (r == TSD_OK) r = launch_pack_tile_major(ctx, wf, C, 5 * C, wf_tm);
+      if (r == TSD_OK) { a->fold_w = wf; a->fold_w_tm = wf_tm; a->fold_b = bf; }
+      off += 2 * wb + ((((size_t)C * 4) + 255) & ~size_t(255));
     }
   }
   ctx->arena.planning = was_planning;

@@ -69,6 +69,9 @@ struct AttnW {  // Unet_Attention_Block, diffusion.mojo:87-98
   // the block is not eligible or the model's parameters changed since the last model_check_ready()
   const half_t* tail_stream = nullptr;
   const half_t* head_stream = nullptr;  // same for conv_in + in_proj (fused head kernel)
+  // derived, blocks that run op by op (C = 640 / 1280): `conv_out(geglu2(h) + r) + x` (diffusion.mojo:143-146) is linear in [h | r], so the two
+  // GEMMs run as ONE over the channel concat with folded weights [C][4C + C] (row-major and K-tile-major) and bias conv_out.w . geglu2.b + conv_out.b
+  const half_t* fold_w = nullptr; const half_t* fold_w_tm = nullptr; const float* fold_b = nullptr;
 };
 // true when the fused tail kernel can run this block's weights (reference norms, tanh GELU, C = 8 x 40)
 bool attn_tail_weights_ok(const AttnW& w);

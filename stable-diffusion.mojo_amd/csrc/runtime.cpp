@@ -23,6 +23,7 @@ void options_from_env(TsdOptions& o) {
   o.gn_composite = env_int("TSD_GN_COMPOSITE", o.gn_composite);
   o.conv_in_im2col = env_int("TSD_CONV_IN_IM2COL", o.conv_in_im2col);
   o.chain = env_int("TSD_CHAIN", o.chain) ? 1 : 0;
+  o.fold_out = env_int("TSD_FOLD_OUT", o.fold_out) ? 1 : 0;
   o.conv_w_tm_mib = env_int("TSD_CONV_W_TM", o.conv_w_tm_mib);
   o.lin_w_tm = env_int("TSD_LIN_W_TM", o.lin_w_tm);
   o.lin_w_tm_kib = env_int("TSD_LIN_W_TM_KIB", o.lin_w_tm_kib);

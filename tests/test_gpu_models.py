@@ -59,6 +59,40 @@ def test_diffusion_forward_matches_oracle_odd_sizes(diffusion, unet_params):
         assert np.array_equal(np.asarray(single).reshape(out[b].shape), out[b]), b
 
 
+def test_folded_geglu2_conv_out_equals_the_two_launches(gpu_ctx, tsd_mod, diffusion, unet_params):
+    """diffusion.mojo:143-146 - `conv_out(geglu2(h) + r) + x` is linear in [h | r]: the op-by-op attention blocks (C = 640 / 1280) run it as ONE
+    GEMM over the channel concat with weights folded at model_check_ready (fp32 sums, one rounding per folded weight; round 6, +0.9 % on the
+    step).  A context created with TSD_FOLD_OUT=0 keeps the two launches: the two paths must differ (the fold skips one fp16 rounding of
+    the M x C intermediate), agree with each other far inside the model tolerance, and both match the oracle."""
+    from tsd._lib import Context
+    from util import rel_l2
+    B, L = 2, 16
+    lat, ctx = _inputs(B, L, tag=540)
+    temb = np.stack([ops.time_embedding(700.0), ops.time_embedding(40.0)])
+    ref = np.stack([models.diffusion(unet_params, lat[b], ctx[b], temb[b]) for b in range(B)])
+    y1 = np.asarray(diffusion.forward(lat, ctx, temb), np.float32)
+    old = os.environ.get("TSD_FOLD_OUT")
+    os.environ["TSD_FOLD_OUT"] = "0"   # read once, by tsd_ctx_create
+    try:
+        ctx_b = Context(gpu_ctx.device)
+    finally:
+        if old is None:
+            os.environ.pop("TSD_FOLD_OUT", None)
+        else:
+            os.environ["TSD_FOLD_OUT"] = old
+    try:
+        other = tsd_mod.Diffusion(seed=SEED, ctx=ctx_b)
+        y0 = np.asarray(other.forward(lat, ctx, temb), np.float32)
+        other.model.close()
+    finally:
+        ctx_b.close()
+    assert_close(y1, ref, TOL_MODEL, TOL_MODEL_MAX, "Diffusion.forward, folded GEGLU-2 + conv_out")
+    assert_close(y0, ref, TOL_MODEL, TOL_MODEL_MAX, "Diffusion.forward, two launches")
+    d = rel_l2(y1, y0)
+    print(f"[parity] folded GEGLU-2 + conv_out vs two launches rel_l2={d:.3e}")
+    assert 0.0 < d <= 2e-3, d
+
+
 def test_device_rng_equals_host_rng(gpu_ctx, tsd_mod, diffusion, unet_params):
     """init_random on the device == uploading the numpy-generated weights: outputs must be bit-identical."""
     full = spec.init_params("diffusion", SEED)  # includes the unused tensors
