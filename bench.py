@@ -14,8 +14,8 @@ only collective is the one-time RCCL broadcast of the packed weights from rank 0
 region).  Rank 0 prints ONE JSON line.
 
 `python bench.py --gpus N` started PLAINLY (no WORLD_SIZE in the environment) launches its own N ranks: it re-executes
-itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per visible
-device.  The line never lies about N: fewer than N visible devices, or a WORLD_SIZE that differs from --gpus, is an error
+itself under `python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N`, one rank per visible
+device (started under mpirun / srun without torchrun's variables it refuses instead of starting N ranks per rank).  The line never lies about N: fewer than N visible devices, or a WORLD_SIZE that differs from --gpus, is an error
 (exit status 2), and `n_gpus` is asserted equal to --gpus before anything is printed; `rccl_ranks` reports the size of the
 communicator that actually ran (torch.distributed's world size, and ncclCommCount on the library's own RCCL path).
 """
@@ -136,7 +136,7 @@ def pmc_traffic_per_gemm_launch():
     with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads -> x2).
     (None, None) when no profile is committed: bench.py itself never runs a profiler, so the figure is NOT measured by
     this run - `traffic_source` in the JSON line says which file it came from."""
-    for name in ("r05_pmc_hbm_traffic.txt", "r04_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
+    for name in ("r06_pmc_hbm_traffic.txt", "r05_pmc_hbm_traffic.txt", "r04_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02_pmc_hbm_traffic.txt", "r01_pmc_hbm_traffic.txt"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             fetch = write = launches = 0.0
@@ -154,11 +154,15 @@ def pmc_traffic_per_gemm_launch():
 
 
 def flash_workgroups_per_step(B, L):
-    """Workgroups of the nine self-attention launches of one UNet step (kernels_attn.hip: 4 waves of 64 queries at d = 40, of 32
-    queries at d = 80 / 160; 8 heads) - the denominator of the exact-repeat fraction."""
+    """Workgroups of the nine self-attention launches of one UNet step - the denominator of the exact-repeat fraction.  d = 40: 512 queries
+    per workgroup on the 8-wave kernel (kernels_attn8.hip: key loops of >= 512 keys with >= 64 workgroups per sample, i.e. L = 64), else
+    4 waves of 64; d = 80 / 160: 4 waves of 32 queries; 8 heads."""
     n, side = 0, L
-    for q_per_wg in (256, 128, 128):
-        n += 3 * B * 8 * max(1, -(-(side * side) // q_per_wg))
+    for level, q_per_wg in enumerate((256, 128, 128)):
+        S = side * side
+        if level == 0 and os.environ.get("TSD_ATTN_WG8", "1") != "0" and S >= 512 and -(-S // 512) * 8 >= 64:
+            q_per_wg = 512
+        n += 3 * B * 8 * max(1, -(-S // q_per_wg))
         side //= 2
     return n
 
@@ -379,7 +383,6 @@ def self_launch(n):
     """`bench.py --gpus N` without a launcher: start N ranks of this same command line under torch.distributed.run, one per visible
     device (TSD_BENCH_DEVICE / TSD_BENCH_BACKEND=gloo - the one-GPU exercise of the N > 1 path - lift the device-count check).
     Returns the exit status to leave with."""
-    import socket
     import subprocess
     one_device = "TSD_BENCH_DEVICE" in os.environ or os.environ.get("TSD_BENCH_LAUNCH_ONLY") == "1"
     if not one_device:
@@ -387,11 +390,10 @@ def self_launch(n):
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible: refusing to run", file=sys.stderr)
             return 2
-    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d store picks the rendezvous port (no bind / close / reuse race on a busy host: ADVICE r05);
+    # --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     print(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:7])} ...", file=sys.stderr)
@@ -445,7 +447,13 @@ def main():
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    # started by another launcher that does not export torchrun's variables (mpirun, srun): every rank would start N more - refuse
+    foreign = [v for v in ("OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS") if int(os.environ.get(v, "1") or 1) > 1]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if foreign:
+            print(f"bench.py: --gpus {args.gpus} under a launcher that sets {foreign[0]} but not RANK / WORLD_SIZE / MASTER_*: start it with "
+                  "torch.distributed.run (or plainly, one process) - refusing to start ranks per rank", file=sys.stderr)
+            sys.exit(2)
         sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -138,10 +138,12 @@ struct tsd_session {
   bool uploaded = false, has_noise = false;
   size_t plan_unet = 0, plan_dec = 0;
   unsigned opt_gen = 0;  // generation of the context's options the workspace was sized for (upload)
-  // Latched when a download found inf / NaN in this session's state (or the context reported TSD_E_NONFINITE at one of this session's
-  // synchronisation points): the context's counter is cleared once reported, the latents stay what they are - every later step,
-  // decode and download of THIS session fails with TSD_E_NONFINITE until upload() replaces the state.
+  // Latched when the host scan of a download found inf / NaN in THIS session's latents: the context's counter is cleared once reported,
+  // the latents stay what they are - every later step, decode and download of this session fails with TSD_E_NONFINITE until upload()
+  // replaces the state.  The context-wide counter alone does not latch it: it also counts other sessions and
+  // models of the context (bench.py's scaled "peaked" model copy); its code is still returned at the synchronisation point that sees it.
   bool poisoned = false;
+  bool decoded = false;  // decode() has run since the last upload(): images are defined
 };
 
 // inf / NaN scan of a downloaded tensor (exponent bits all ones); the buffers at this boundary are 0.5 - 25 MB
@@ -292,6 +294,7 @@ extern "C" int tsd_session_upload(tsd_session* s, const float* latents, const fl
   s->opt_gen = ctx->opt.gen;
   s->uploaded = true;
   s->poisoned = false;
+  s->decoded = false;
   return TSD_OK;
 }
 
@@ -362,29 +365,29 @@ extern "C" int tsd_session_decode(tsd_session* s) {
   s->ctx->arena.top = 0;
   int r = g_decoder_forward(s->dec, s->latents, s->B, s->L, s->images);
   s->ctx->arena.top = 0;
+  if (r == TSD_OK) s->decoded = true;
   return r;
 }
 
 extern "C" int tsd_session_download_latents(tsd_session* s, float* latents) {
   NOTNULL(s); NOTNULL(latents);
+  if (!s->uploaded) TSD_FAIL(TSD_E_STATE, "session: upload() before download_latents() (the state is not defined yet)");
   const size_t n = (size_t)s->B * 4 * s->L * s->L;
   HIP_TRY(hipMemcpyAsync(latents, s->latents, n * 4, hipMemcpyDeviceToHost, s->ctx->stream));
   HIP_TRY(hipStreamSynchronize(s->ctx->stream));
   const int r = ctx_check_status(s->ctx);
-  if (r == TSD_E_NONFINITE) s->poisoned = true;
+  // what leaves the device HERE is checked itself: the context's count may have been reported (and cleared) at another model's
+  // synchronisation point, and it may be another session's - only this session's own buffer latches the poison
+  if (!host_all_finite(latents, n)) s->poisoned = true;
   if (r != TSD_OK) return r;
-  // the context's count may have been reported (and cleared) at another model's synchronisation point, or by an earlier call: what
-  // leaves the device HERE is checked itself
-  if (s->poisoned || !host_all_finite(latents, n)) {
-    s->poisoned = true;
-    SESSION_NOT_POISONED(s);
-  }
+  SESSION_NOT_POISONED(s);
   return TSD_OK;
 }
 
 extern "C" int tsd_session_download_images(tsd_session* s, int rescale_0_255, float* images) {
   NOTNULL(s); NOTNULL(images);
   if (!s->dec) TSD_FAIL(TSD_E_STATE, "session: created without a decoder");
+  if (!s->decoded) TSD_FAIL(TSD_E_STATE, "session: decode() before download_images() (no image has been computed since upload())");
   tsd_ctx* ctx = s->ctx;
   const int64_t n = (int64_t)s->B * 3 * 64 * s->L * s->L;
   const float* src = s->images;
@@ -396,12 +399,10 @@ extern "C" int tsd_session_download_images(tsd_session* s, int rescale_0_255, fl
   HIP_TRY(hipMemcpyAsync(images, src, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const int r = ctx_check_status(ctx);
-  if (r == TSD_E_NONFINITE) s->poisoned = true;
   if (r != TSD_OK) return r;
-  if (s->poisoned || !host_all_finite(images, (size_t)n)) {
-    s->poisoned = true;
-    SESSION_NOT_POISONED(s);
-  }
+  SESSION_NOT_POISONED(s);
+  // a non-finite IMAGE is reported, it does not poison latents that may be fine (decode again after the cause is removed)
+  if (!host_all_finite(images, (size_t)n)) TSD_FAIL(TSD_E_NONFINITE, "session: inf / NaN in the decoded images");
   return TSD_OK;
 }
 

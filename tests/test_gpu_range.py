@@ -33,6 +33,11 @@ def diffusion(gpu_ctx, tsd_mod):
     return tsd_mod.Diffusion(seed=1234)  # device-side counter-RNG init (as tests/test_gpu_models.py)
 
 
+@pytest.fixture(scope="module")
+def decoder(gpu_ctx, tsd_mod):
+    return tsd_mod.Decoder(seed=1234)
+
+
 def _conv_at(tsd, target, C=64, O=64, H=16, k=3, split=10.0):
     """Conv2D whose largest |output| is `target`: the amplitude is split between the weights (x `split`) and the input so that both
     operands stay inside fp16 as well."""
@@ -235,6 +240,38 @@ def test_module_forward_overflow_is_reported(gpu_ctx, tsd_mod, diffusion):
     assert np.isfinite(sess.latents()).all()
     sess.close()
     assert lib().tsd_debug_nonfinite_count(gpu_ctx.h, 1) >= 0
+
+
+def test_session_downloads_need_defined_state_and_only_own_data_poisons(gpu_ctx, tsd_mod, diffusion, decoder):
+    """a download of state that was never written is TSD_E_STATE, not a host scan of uninitialised device memory that may
+    latch the poison; and inf / NaN produced by ANOTHER model of the same context (reported through the context-wide counter at this
+    session's next synchronisation point) is returned once but does not poison this session, whose own latents are finite."""
+    from tsd._lib import TSD_E_NONFINITE, TSD_E_STATE
+    B, L, T = 1, 8, 77
+    sess = tsd_mod.Session(diffusion.model, decoder.model, B, L, T, cfg=False)
+    sess.set_schedule(1000, 2, 0)
+    with pytest.raises(tsd_mod.TsdError) as e0:
+        sess.latents()
+    assert e0.value.code == TSD_E_STATE
+    lat, ctx = randn(440, B, 4, L, L), randn(441, B, T, 768)
+    sess.upload(lat, ctx, None, None)
+    with pytest.raises(tsd_mod.TsdError) as e1:
+        sess.images()
+    assert e1.value.code == TSD_E_STATE          # no decode() yet
+    sess.step(0)
+    # another model on the same context overflows: the context-wide counter is non-zero at this session's next synchronisation point
+    with pytest.raises(tsd_mod.TsdError):
+        diffusion.forward(lat * np.float32(1e6), ctx, tsd_mod.get_time_embedding(500.0).reshape(1, 320))
+    try:
+        got = sess.latents()                     # either clean (the module call reported and cleared the counter) ...
+    except tsd_mod.TsdError as ex:               # ... or the context's code, once
+        assert ex.code == TSD_E_NONFINITE
+        got = sess.latents()                     # not latched: this session's latents are finite
+    assert np.isfinite(got).all()
+    sess.step(1)
+    sess.decode()
+    assert np.isfinite(sess.images()).all()
+    sess.close()
 
 
 # ---- two contexts, two threads, different settings (SURVEY.md section 8b "Threading") -----------------------------------------
