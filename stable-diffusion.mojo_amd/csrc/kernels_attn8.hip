@@ -20,15 +20,17 @@
 //     chain ~10 clocks each.  A wave's OWN VALU work between its MFMAs always adds.
 // So a wave alternates between
 //   * an X phase (no MFMA): this wave's LDS-DMA pieces of key tile t+2, the eight V^T fragment reads of tile t, the exponentials + converts
-//     that turn query block 0's scores S(t) into P(t), and
-//   * an M phase (28 MFMAs, priority 1 with a flip behind each): per query block P(t).V(t) (8) then K(t+1).Q^T (6); query block 1's
-//     exponentials ride between the first eighteen MFMAs (a split found by measurement: all 64 in the X phase make it the longer phase),
-//     the six K(t+1) fragment reads go out behind the first MFMA,
+//     that turn the first three chunks of query block 0's scores S(t) into P(t) (24 of the tile's 64 exponentials), and
+//   * an M phase (28 MFMAs at priority 1): per query block P(t).V(t) (8) then K(t+1).Q^T (6); query block 0's last chunk rides behind the first
+//     four MFMAs, query block 1's 32 exponentials between MFMAs 4..17, and behind each of the last ten - which carry no VALU work of their own -
+//     the wave drops to priority 0 for one instruction (the split and the flip placement found by measurement, profiles/r06_attn8_*: all 64
+//     exponentials in the X phase make it the long pole, flips behind every MFMA cost 50 clocks per tile more); the six K(t+1) fragment reads
+//     go out behind the first MFMA,
 // and waves 0-3 / 4-7, which sit pairwise on the four SIMDs, run the two phases in opposition under two s_barrier per tile.  All eight waves
 // share each K / V^T tile (512 queries per workgroup: half the LDS-DMA per query of the 4-wave kernel); 3-slot ring; group 0 issues the five
 // 1-KiB DMA instructions of a K tile, group 1 those of a V^T tile (one per wave, a second one on each group's first wave) behind counted waits.
-// Measured (profiles/r06_attn8_*.txt): 4096 x 4096, B*H = 64: 2590 clocks per key tile and SIMD against 3230 for flash_attn_kernel<40, 2>;
-// 6 % less time on the same box (the chip gives part of the cycle saving back as clock).
+// Measured (profiles/r06_attn8_*.txt): 4096 x 4096, B*H = 64: 2500 clocks per key tile and SIMD against 3230 for flash_attn_kernel<40, 2>;
+// 6-9 % less time on the same box (the chip gives most of the cycle saving back as clock).
 //
 // Ring protocol (h = half periods; group 0: X(t) at h = 2t, M(t) at 2t+1; group 1: X(t) at 2t+1, M(t) at 2t+2):
 //   K(t+2) is issued by group 0 at the start of X(t), waited for (counted: the pieces of tile t+3 stay in flight) at the end of X(t+1),
@@ -46,9 +48,10 @@
 
 // variant bits (timing / A-B builds, -DTSD_ATTN8_VARIANTS): 1 = static s_setprio(1) for waves 4-7, 2 = s_setprio(1) around every M phase,
 // 4 = no exponentials (timing only), 8 = no MFMAs (timing only), 16 x n = n of query block 1's four chunks exponentiated in the X phase,
-// 128 = priority flip behind every MFMA of the M phase, 256 = V^T fragment reads at the start of the X phase
+// 128 = priority flip behind every MFMA of the M phase, 256 = V^T fragment reads at the start of the X phase, 512 = flips only behind the MFMAs
+// without own exponentials, 1024 = query block 0's fourth chunk exponentiated in the M phase
 #ifndef TSD_ATTN8_DEFAULT_VAR
-#define TSD_ATTN8_DEFAULT_VAR 384  // shipped: priority flips in the M phase + V^T fragments at the start of the X phase
+#define TSD_ATTN8_DEFAULT_VAR 1920  // shipped: 128 + 256 + 512 + 1024 (flips behind the MFMAs that carry no own VALU work, V^T fragments first, X 24 + M 40 exponentials)
 #endif
 #ifdef TSD_ATTN8_TS
 __device__ unsigned long long g_attn8_ts[256 * 8 * 4];  // per (block < 256, wave): ticks in X, at barrier 1, in M, at barrier 2
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
   constexpr int XCH = (VAR >> 4) & 7;  // chunks (of 4) of query block 1 exponentiated in the X phase; the others between the M phase's MFMAs
   static_assert(XCH <= 4, "variant");
   constexpr bool VF_EARLY = (VAR & 256) != 0;  // V^T fragment reads at the start of the X phase instead of behind the exponentials
+  constexpr bool Q0LATE = (VAR & 1024) != 0;  // query block 0's fourth chunk exponentiated in the M phase (X 24 + M 40 instead of 32 + 32)
   constexpr bool FLIP = (VAR & 128) != 0;  // priority 1 in the M phase, dropped for one instruction behind every MFMA
   constexpr int DCH = D / 8, KSTEPS = (DCH + 1) / 2, KPITCH = (DCH & 1) ? DCH : ((2 * KSTEPS) | 1);
   constexpr int DBLK = (D + 31) / 32, VROWS = DBLK * 32;
@@ -353,13 +357,14 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
         pf[qb][kq][e + 1] = (half_t)p1;
       };
       constexpr int XP = 4 * XCH;  // pairs of query block 1 done in the X phase
+      constexpr int X0 = Q0LATE ? 12 : 16;  // pairs of query block 0 done here (Q0LATE: its last chunk rides behind the first four MFMAs of the M phase)
 #pragma unroll
-      for (int pr = 0; pr < 16; pr++) p_pair(0, pr);
+      for (int pr = 0; pr < X0; pr++) p_pair(0, pr);
 #pragma unroll
       for (int pr = 0; pr < XP; pr++) p_pair(1, pr);
       // complete in front of barrier 1: without the (empty) uses hipcc sinks exponentials into the M phase
 #pragma unroll
-      for (int kq = 0; kq < 4; kq++) asm volatile("" : "+v"(pf[0][kq]));
+      for (int kq = 0; kq < X0 / 4; kq++) asm volatile("" : "+v"(pf[0][kq]));
 #pragma unroll
       for (int kq = 0; kq < XCH; kq++) asm volatile("" : "+v"(pf[1][kq]));
       __builtin_amdgcn_sched_barrier(0);
@@ -424,13 +429,16 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
         // and converts then run AFTER the MFMAs, not under them (scripts/micro/valu_port.hip: 28 MFMAs next to 64 exp + 32 cvt take 1410-1610
         // clocks, the sum).  Dropping to priority 0 for one instruction behind every MFMA hands the partner the issue slots of the ~28 clocks
         // the pipe is busy anyway: 1190 clocks for both, whichever wave is older (the flip itself costs the MFMA chain ~10 clocks each).
-        if constexpr (FLIP) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_s_setprio(1); }
+        if constexpr (FLIP) { if (!(VAR & 512) || i >= EXP_SLOTS) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_s_setprio(1); } }  // (512: only behind MFMAs that carry none of the wave's own exponentials)
         if constexpr (MORE) {
           if (i == 0) k_frags(nx1, kf);
         }
+        if constexpr (Q0LATE) {  // query block 0's last chunk: needed by slot 6, its scores are overwritten from slot 8
+          if (i < 4) p_pair(0, 12 + i);
+        }
 #pragma unroll
         for (int pr = XP; pr < 16; pr++)
-          if (((pr - XP) * EXP_SLOTS) / (16 - XP) == i) p_pair(1, pr);
+          if ((Q0LATE ? 4 : 0) + ((pr - XP) * (EXP_SLOTS - (Q0LATE ? 4 : 0))) / (16 - XP) == i) p_pair(1, pr);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr ((VAR & 2) || FLIP) __builtin_amdgcn_s_setprio(0);
@@ -530,13 +538,10 @@ int launch_flash_attention8(tsd_ctx* ctx, const AttnK& k, int B, int H, int Sq, 
   if (d != 40) TSD_FAIL(TSD_E_SHAPE, "8-wave flash attention: head dim %d unsupported", d);
   switch (variant) {
 #ifdef TSD_ATTN8_VARIANTS  // timing / A-B builds only
-    case 128: return launch_fa8<40, 128>(ctx, k, B, H, Sq);
-    case 160: return launch_fa8<40, 160>(ctx, k, B, H, Sq);
-    case 192: return launch_fa8<40, 192>(ctx, k, B, H, Sq);
-    case 256: return launch_fa8<40, 256>(ctx, k, B, H, Sq);
     case 384: return launch_fa8<40, 384>(ctx, k, B, H, Sq);
-    case 416: return launch_fa8<40, 416>(ctx, k, B, H, Sq);
-    case 448: return launch_fa8<40, 448>(ctx, k, B, H, Sq);
+    case 896: return launch_fa8<40, 896>(ctx, k, B, H, Sq);
+    case 1920: return launch_fa8<40, 1920>(ctx, k, B, H, Sq);
+    case 1408: return launch_fa8<40, 1408>(ctx, k, B, H, Sq);
 #endif
     default: return launch_fa8<40, TSD_ATTN8_DEFAULT_VAR>(ctx, k, B, H, Sq);
   }
