@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256, D == 40 ? 6 - 2 * QB : 2) void flash_attn_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #elif TSD_ATTN_ABL & 64 // ablation: neither the DMA wait nor the barrier
 #else
+    // (the EXACT pass never consults the flag - `check` is false there - so the word needs no reset between the passes: ADVICE r05)
     const bool check = !EXACT && ONES_ROW && (t % CHECK_EVERY) == CHECK_EVERY - 1 && t + 1 < ntiles;  // uniform
     if constexpr (!EXACT && ONES_ROW) {
       if (check) {
