@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
     }
   }
 
-  // ---- this wave's two DMA instructions per tile: group 0 the K tile, group 1 the V^T tile -------------------------
+  // ---- this wave's one or two DMA instructions per tile: group 0 the K tile, group 1 the V^T tile -------------------
   // K tile: slot = row*KPITCH + pos; LDS row `row` holds key k0 + pi(row), pi swaps bits 2 and 3 (a lane's 8 probabilities per k-step are
   // then 8 consecutive keys); keys >= Sk fall outside the descriptor and read as zeros.  V^T tile: slot = R*8 + pos, pos holds logical
   // chunk pos ^ ((R>>1)&7); chunks past the last valid key of the last tile are padded by their own offset set.
@@ -223,8 +223,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn8_kernel(const AttnK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // S^T(t) - ref = K(t) . Q^T + (-ref): two 32-key blocks per query block, the six K fragments read once
-    // the six K fragments of a tile; in the last k-step the hi = 1 lanes hold the pad chunk (columns 40..47): they read the slot's constant block
+    // the six K fragments of a tile (S^T(t) - ref = K(t) . Q^T: two 32-key blocks per query block, fragments shared by both query blocks); in the last k-step the hi = 1 lanes hold the pad chunk (columns 40..47): they read the slot's constant block
     auto k_frags = [&](int buf, h8 (&kf)[KSTEPS][2]) {
       const char* sK = smem + buf * BUF_BYTES;
 #pragma unroll
